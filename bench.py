@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 388x388 patches/s of the fused forward + backward + Momentum step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload = BASELINE.json configs[1]: num_layers=5 root_size=64 patch_size=388 (input 572), bf16 storage / fp32
+accumulate, 4 patches per GPU (weak scaling: the global batch is 4*N), synthetic data of SURVEY.md section 8(d):
+X ~ U[0,1), labels ~ Bernoulli(0.2), Glorot-uniform weights, lr 0.01, momentum 0.9, dropout_keep 1.0. A step is
+session.run([train, loss, predictions]) of the reference (tf_aerial_images.py:241-244): forward, loss, full backward,
+gradient all-reduce over RCCL when N > 1, Momentum update of every live variable and the bf16 re-pack of the weights.
+Inputs are resident in HBM before the timed region (the reference feeds host numpy arrays; the PCIe-inclusive figure is
+discussed in DESIGN.md and is never `value`).
+
+Besides the contract line the JSON carries
+  roofline     : the 3x3-conv MFMA kernels (igemm_fwd = forward + backward-data, igemm_wgrad = backward-weight):
+                 algorithmic FLOPs (2*B*Ho*Wo*Cout*Cin*9 per launch) / HIP-event time of those launches,
+                 measured in an instrumented pass right after the timed region on the launch stream; peak = 2.5 PFLOP/s
+                 dense bf16 MFMA (/opt/skills/guides/MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (oracle/unet_oracle.c, kind "port"; TensorFlow 1.4 cannot be installed) timed on the
+                 host cores on a bounded sample of the same network, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from road_segmentation_unet_amd.dist import GradBucketer  # noqa: E402
+from road_segmentation_unet_amd.unet import UNet, input_size_needed  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def run_step(m, bucketer, lr, mu):
+    m.forward_device()
+    if bucketer is not None:
+        bucketer.reset()
+    m.backward_device(m._inv_count)
+    if bucketer is not None:
+        bucketer.finish()
+    m.apply_momentum(lr, mu)
+
+
+def cpu_baseline(L, root, sample_P, conv_gflop_per_388_patch_total):
+    """Oracle (C port of the reference's graph) on the host cores: one fwd+bwd+Momentum step on a bounded sample."""
+    from oracle import unet_oracle as U
+    S = U.input_size_needed(sample_P, L)
+    rng = np.random.RandomState(2017)
+    X = rng.rand(1, S, S, 3).astype(np.float32)
+    labels = (rng.rand(1, sample_P, sample_P) < 0.2).astype(np.int64)
+    params = U.init_params(L, root, False, seed=2018)
+    acc = {k: np.zeros_like(v) for k, v in params.items()}
+    U.lib()
+    t0 = time.time()
+    U.train_step(params, acc, X, labels, L, root, False)
+    dt = time.time() - t0
+    return dt, S
+
+
+def net_flops(L, root, dilated, P, B):
+    """algorithmic FLOPs of one fwd+bwd step: (total, 3x3 convs) following BASELINE.md section 2 (dead ops excluded)."""
+    S = input_size_needed(P, L)
+    tot = conv3 = 0.0
+    h, nf, cin = S, root, 3
+    tot += 2 * 2.0 * B * S * S * 3 * 3  # color adjust: fwd + bwd-weight only
+    enc = []
+    for i in range(L):
+        last = i == L - 1
+        f1 = 2.0 * B * (h - 2) ** 2 * nf * cin * 9
+        f2 = 2.0 * B * (h - 4) ** 2 * nf * nf * 9
+        mult1 = 2 if i == 0 else 3  # no bwd-data into the 3-channel input
+        conv3 += mult1 * f1 + 3 * f2
+        if dilated and not last:
+            d1 = 2.0 * B * (h - 4) ** 2 * nf * cin * 9
+            d2 = 2.0 * B * (h - 8) ** 2 * nf * nf * 9
+            conv3 += mult1 * d1 + 3 * d2
+        enc.append((h - 4, nf))
+        if not last:
+            h = (h - 4) // 2
+            cin, nf = nf, nf * 2
+    h = h - 4
+    up = 0.0
+    for i in range(L - 1):
+        nf //= 2
+        up += 3 * 2.0 * B * h * h * 4 * nf * (2 * nf)
+        h *= 2
+        ccat = (3 if dilated else 2) * nf
+        conv3 += 3 * (2.0 * B * (h - 2) ** 2 * nf * ccat * 9 + 2.0 * B * (h - 4) ** 2 * nf * nf * 9)
+        h -= 4
+    head = 3 * 2.0 * B * P * P * root * 2
+    tot += conv3 + up + head
+    return tot, conv3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--num_layers", type=int, default=5)
+    ap.add_argument("--root_size", type=int, default=64)
+    ap.add_argument("--patch_size", type=int, default=388)
+    ap.add_argument("--batch_per_gpu", type=int, default=4)
+    ap.add_argument("--dilated_layers", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_sample_patch", type=int, default=260)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    L, root, P, B = args.num_layers, args.root_size, args.patch_size, args.batch_per_gpu
+    S = input_size_needed(P, L)
+    m = UNet(L, root, args.dilated_layers, B, P, device=dev, seed=2018, training=True)
+    m._inv_count = 1.0 / (world * B * P * P)
+    g = torch.Generator(device="cpu").manual_seed(2017 + rank)
+    m.x.copy_(torch.rand((B, S, S, 3), generator=g))
+    m.labels.copy_((torch.rand((B, P, P), generator=g) < 0.2).to(torch.int64))
+    bucketer = None
+    if world > 1:
+        bucketer = GradBucketer(m.flat_g, m.n_live)
+        m.on_grads = bucketer.ready
+    lr, mu = 0.01, 0.9
+
+    for _ in range(args.warmup):
+        run_step(m, bucketer, lr, mu)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(m, bucketer, lr, mu)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(m.loss_sum.item()) * m._inv_count * 1.0
+
+    # ---- instrumented pass (HIP events on the launch stream around every 3x3-conv MFMA launch)
+    nprof = 3
+    m.prof = []
+    for _ in range(nprof):
+        run_step(m, bucketer, lr, mu)
+    torch.cuda.synchronize()
+    agg = {}
+    for tag, fl, e0, e1 in m.prof:
+        a = agg.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    m.prof = None
+    conv_fl = sum(a[0] for a in agg.values())
+    conv_t = sum(a[1] for a in agg.values())
+    n_launch = sum(a[2] for a in agg.values())
+    achieved = conv_fl / conv_t / 1e12 if conv_t > 0 else 0.0
+    tot_fl, conv3_fl = net_flops(L, root, args.dilated_layers, P, B)
+
+    out = {
+        "metric": "388x388 patches/sec fwd+bwd (1/2/4/8 GPU) + conv MFMA % of peak",
+        "value": world * B * args.steps / dt,
+        "unit": "patches/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "U-Net fwd+bwd+momentum step, num_layers=%d root_size=%d patch_size=%d input=%d%s" %
+                               (L, root, P, S, " dilated" if args.dilated_layers else ""),
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "step_tflops_algorithmic": tot_fl * world * args.steps / dt / 1e12, "loss": loss},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "3x3 conv MFMA kernels: igemm_fwd (fwd, bwd-data) + igemm_wgrad",
+                     "launches_per_step": n_launch // nprof,
+                     "avg_launch_us": conv_t / max(1, n_launch) * 1e6,
+                     "conv_ms_per_step": conv_t / nprof * 1e3,
+                     "algorithmic_gflop_per_step": conv_fl / nprof / 1e9,
+                     "by_kernel": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / nprof * 1e3, "launches": v[2] // nprof}
+                                   for k, v in agg.items()}},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cdt, cS = cpu_baseline(L, root, args.cpu_sample_patch, None)
+            sample_fl, _ = net_flops(L, root, False, args.cpu_sample_patch, 1)
+            full_fl, _ = net_flops(L, root, False, P, 1)
+            out["cpu_baseline"] = {"value": (sample_fl / full_fl) / cdt, "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "oracle/unet_oracle.c (OpenMP, fp32 data / fp64 accumulate), one fwd+bwd+momentum step of the "
+                                             "same L=%d root=%d network on one %dx%d-output patch (input %d) = %.1f GFLOP in %.1f s, "
+                                             "scaled by algorithmic FLOPs to 388-patch equivalents" %
+                                             (L, root, args.cpu_sample_patch, args.cpu_sample_patch, cS, sample_fl / 1e9, cdt),
+                                   "gflops": sample_fl / cdt / 1e9}
+        except Exception as ex:  # the baseline is reported, never required for the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "patches/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (ex,)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

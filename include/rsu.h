@@ -1,0 +1,167 @@
+/*
+ * rsu.h -- C ABI of the MI355X-native U-Net hot path (librsu_hip.so).
+ *
+ * The reference (aschneuw/road-segmentation-unet) is pure Python over TensorFlow 1.4; it has no
+ * FFI of its own. The operator boundary this library replaces is the set of TF op kernels that
+ * /root/reference/src/unet.py:12-97 and src/tf_aerial_images.py:103-122,147-149 instantiate, plus
+ * the numpy tiler of src/images.py. Every entry point below cites the reference call site it
+ * stands in for. INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch / C++ types. `stream` is a hipStream_t passed
+ *     as void* (NULL = the default stream). All calls are asynchronous on that stream and
+ *     re-entrant per stream; the library keeps no per-call global state.
+ *   - activations: NHWC, bfloat16 ("bf16", the storage type of the fast path), raw uint16 bits.
+ *     Channel counts of bf16 tensors must be multiples of 8 (16-byte pieces).
+ *   - parameters / gradients / optimizer state: float32 in the reference's own layouts: conv
+ *     kernels HWIO [kh][kw][Cin][Cout] (tf.layers.conv2d), transposed-conv kernels
+ *     [kh][kw][Cout][Cin] (tf.layers.conv2d_transpose).
+ *   - MFMA kernels read bf16 copies of the weights in "fragment order" produced by the
+ *     rsu_pack_* calls (re-pack after every optimizer step).
+ *   - return value: 0 on success, negative errno-style code otherwise (never throws).
+ */
+#ifndef RSU_H_
+#define RSU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSU_OK 0
+#define RSU_EINVAL (-22)  /* bad geometry / unsupported shape (the reference raises AssertionError) */
+#define RSU_ENOMEM (-12)  /* workspace too small */
+#define RSU_EHIP (-5)     /* a HIP runtime call failed; see rsu_last_hip_error() */
+
+typedef void* rsu_stream_t; /* hipStream_t */
+
+/* One input of a (virtually concatenated) convolution: a window of an NHWC bf16 tensor.
+ * unet.py:70-85 crops the skip tensor(s) to the up-conv size and concatenates [skip,(dil skip),up]
+ * on the channel axis; this library never materialises that tensor: the conv reads up to three
+ * sources, each with its own crop offset (oy, ox) = ((H - h) / 2, (W - w) / 2). */
+typedef struct {
+    const void* ptr; /* bf16 [N][H][W][C] */
+    int H, W, C;
+    int oy, ox; /* origin of the window inside the tensor */
+} rsu_src_t;
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char* rsu_version(void);
+int rsu_last_hip_error(void);
+/* unet.py:100-115 input_size_needed(output_size, num_layers). RSU_EINVAL where the reference asserts. */
+int rsu_input_size_needed(int output_size, int num_layers, int* input_size);
+
+/* ---- weight packing (float32 reference layout -> bf16 MFMA fragment order) -------------- */
+/* Bytes of a packed buffer: taps * roundup(sum_i roundup(seg_c[i],32)) * roundup(rows,64) * 2 */
+size_t rsu_packed_bytes(int taps, int rows, const int* seg_c, int nseg);
+/* conv forward (unet.py:34-45,88-91): A[tap][co][ci]; seg_c = channel count of each concat source */
+int rsu_pack_conv_fwd(const float* w_hwio, void* packed, int k, int Cin, int Cout, const int* seg_c, int nseg,
+                      rsu_stream_t stream);
+/* conv backward-data (Conv2DBackpropInput): A[flipped tap][ci][co] for the input channels
+ * [ci_off, ci_off+ci_cnt) of a kernel with Cin_total inputs (one pack per concat source) */
+int rsu_pack_conv_bwd(const float* w_hwio, void* packed, int k, int Cin_total, int ci_off, int ci_cnt, int Cout,
+                      rsu_stream_t stream);
+/* transposed conv forward (unet.py:67-68): four 1x1 matrices A[a*2+b][co][ci] */
+int rsu_pack_convT_fwd(const float* k_hwoi, void* packed, int Cin, int Cout, rsu_stream_t stream);
+/* transposed conv backward-data: A[a*2+b][ci][co] */
+int rsu_pack_convT_bwd(const float* k_hwoi, void* packed, int Cin, int Cout, rsu_stream_t stream);
+
+/* ---- network head / tail (VALU kernels) -------------------------------------------------- */
+/* unet.py:22-23  net = conv1x1(X - 0.5) (color_space_adjust). x: f32 [npix][3].
+ * out16: bf16 [npix][16] = {net0[0..2], 0, (x-0.5)[0..2], 0, 0 x 8} -- channels 0..2 feed the first
+ * 3x3 conv, channels 4..6 are kept for the weight gradient of color_space_adjust. */
+int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix,
+                         rsu_stream_t stream);
+/* unet.py:34-35,42-43 first 3x3 conv of level 0 (Cin = 3) + bias + ReLU, dil = 1 or 2 (dilated branch).
+ * in16 as above [N][H][W][16]; w f32 HWIO [3][3][3][Cout]; y bf16 [N][H-2d][W-2d][Cout]. */
+int rsu_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout,
+                       int dil, rsu_stream_t stream);
+/* weight/bias gradients of that conv and, through it, of color_space_adjust:
+ * dw1 [3][3][3][Cout], gxc [3][3][3][Cout] where gxc[t][ci][co] = sum_pix (x-0.5)[pix+t][ci] dz[pix][co].
+ * ws: float workspace of rsu_conv_first_bwd_ws_floats() floats. */
+size_t rsu_conv_first_bwd_ws_floats(int Cout);
+int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* ws, int N, int H,
+                              int W, int Cout, int dil, rsu_stream_t stream);
+/* unet.py:95 weight_output 1x1 conv (C -> 2) fused with tf_aerial_images.py:147-148 softmax[...,1].
+ * act bf16 [npix][C]; w f32 [C][2]; prob f32 [npix]; logits f32 [npix][2] or NULL (unet.forward's return value). */
+int rsu_head_fwd(const void* act, const float* w, const float* b, float* prob, float* logits, long npix, int C,
+                 rsu_stream_t stream);
+/* Same plus tf_aerial_images.py:103-110 mean sparse softmax cross-entropy and its backward:
+ * labels int64 [npix] in {0,1}; loss_sum f32[1] (+= sum of per-pixel losses; caller zeroes it);
+ * dact bf16 [npix][C] = gradient wrt the PRE-activation of the last conv2 (ReLU mask applied),
+ * scaled by inv_count (1 / global pixel count); dw f32 [C][2], db f32 [2] (overwritten).
+ * ws: rsu_head_ws_floats(npix, C) floats. */
+size_t rsu_head_ws_floats(long npix, int C);
+int rsu_head_fwd_bwd(const void* act, const float* w, const float* b, const int64_t* labels, float* prob,
+                     float* loss_sum, void* dact, float* dw, float* db, float* ws, long npix, int C,
+                     float inv_count, rsu_stream_t stream);
+
+/* ---- 3x3 convolution, MFMA implicit GEMM -------------------------------------------------- */
+/* unet.py:34-39,42-45,88-91: y = relu(conv3x3_valid(concat(srcs), W, dilation) + b).
+ * All sources share the window size (Hin, Win); y is bf16 [N][Hin-2d][Win-2d][Cout]. */
+int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
+                   int Hin, int Win, int Cout, int dil, int relu, rsu_stream_t stream);
+/* Conv2DBackpropInput for input channels [ci_off, ci_off+ci_cnt) of a conv with Cin_total inputs:
+ * dx bf16 [N][H][W][ci_cnt] (H, W = conv input size), dz bf16 [N][H-2d][W-2d][Cout].
+ * relu_src (optional, same shape as dx): dx *= (relu_src > 0)  -- ReluGrad of the producing layer.
+ * accumulate != 0: dx += result (two consumers of one tensor, unet.py:32-45). */
+int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate,
+                        int N, int H, int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil,
+                        rsu_stream_t stream);
+/* Conv2DBackpropFilter for the input channels held by `src` (rows [ci_off, ci_off+src.C) of dw):
+ * dw f32 HWIO [3][3][Cin_total][Cout] (only those rows are written). (Ho, Wo) = size of dz.
+ * ws: rsu_conv2d_bwd_weight_ws_floats() floats of scratch (split-K slabs). */
+size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout);
+int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* ws, int N, int Ho, int Wo,
+                          int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream);
+/* BiasAddGrad: db[c] = sum over npix of dz[pix][c]. ws: rsu_bias_grad_ws_floats(npix, C) floats. */
+size_t rsu_bias_grad_ws_floats(long npix, int C);
+int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_stream_t stream);
+
+/* ---- 2x2 max pool -------------------------------------------------------------------------- */
+/* unet.py:52 max_pooling2d (2,2)/(2,2) VALID. x bf16 [N][H][W][C] -> y [N][H/2][W/2][C] */
+int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, rsu_stream_t stream);
+/* Gradient junction at an encoder output y_act (ReLU output, bf16 [N][H][W][C]):
+ *   g = MaxPoolGrad(y_act, dpool)            (dpool bf16 [N][H/2][W/2][C], may be NULL)
+ *     + zero-pad(dskip)                      (dskip bf16 [N][Hs][Ws][C] centred, may be NULL;
+ *                                             adjoint of the centre crop of unet.py:70-83)
+ *   dz = g * (y_act > 0)                     (ReluGrad) -> bf16 [N][H][W][C]
+ * MaxPoolGrad routes to the first maximum of the window in row-major order. */
+int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W,
+                           int C, int Hs, int Ws, rsu_stream_t stream);
+
+/* ---- 2x2 stride-2 transposed convolution (unet.py:67-68) ---------------------------------- */
+int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W,
+                     int Cin, int Cout, rsu_stream_t stream);
+/* dx bf16 [N][H][W][Cin] = sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci], times (relu_src > 0) if given */
+int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, int N, int H,
+                          int W, int Cin, int Cout, rsu_stream_t stream);
+/* dK f32 [2][2][Cout][Cin]; ws: rsu_convT2x2_bwd_weight_ws_floats() floats */
+size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout);
+int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin,
+                            int Cout, rsu_stream_t stream);
+
+/* ---- optimizer (tf_aerial_images.py:116-121, MomentumOptimizer, use_nesterov=False) ------- */
+/* acc = mu*acc + gscale*g ; w -= lr*acc. gscale folds the 1/world_size of data-parallel averaging. */
+int rsu_momentum_step(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n,
+                      rsu_stream_t stream);
+
+/* ---- patch / stride tiler (src/images.py) -------------------------------------------------- */
+/* images.py:269-281 mirror_border + :35-85 extract_patches fused, on device: tile t (x-outer,
+ * y-inner order, images.py:76-77) of image n is the [S][S] window of the symmetric-padded image at
+ * origin (x0, y0) = ((t / pps) * stride, (t % pps) * stride). imgs f32 [nimg][H][H][3];
+ * tiles f32 [ntiles][S][S][3] for tile indices [t0, t0+ntiles) of the flattened (img, t) list. */
+int rsu_extract_tiles(const float* imgs, float* tiles, int nimg, int H, int S, int P, int stride, long t0,
+                      long ntiles, rsu_stream_t stream);
+/* images.py:131-164 images_from_patches, accumulation half: acc[n][y0+i][x0+j] += prob[t][i][j],
+ * hits += 1 (f32 accumulators [nimg][H][H]; the division is rsu_overlap_finish). */
+int rsu_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, long t0,
+                    long ntiles, rsu_stream_t stream);
+int rsu_overlap_finish(const float* acc, const float* hits, float* out, long n, rsu_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSU_H_ */

@@ -1,0 +1,87 @@
+"""ctypes binding of librsu_hip.so (the C ABI of include/rsu.h).
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback anywhere in this package. If the
+shared object is missing or a symbol cannot be resolved, importing/using the product path raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsu_hip.so")
+
+_vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+
+class RsuSrc(ctypes.Structure):
+    """rsu_src_t: one (cropped) NHWC bf16 input of a virtually concatenated conv."""
+    _fields_ = [("ptr", _vp), ("H", _i), ("W", _i), ("C", _i), ("oy", _i), ("ox", _i)]
+
+
+_PS = ctypes.POINTER(RsuSrc)
+_PI = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); mirrors include/rsu.h one to one
+SIGNATURES = {
+    "rsu_version": (ctypes.c_char_p, []),
+    "rsu_last_hip_error": (_i, []),
+    "rsu_input_size_needed": (_i, [_i, _i, _PI]),
+    "rsu_packed_bytes": (_sz, [_i, _i, _PI, _i]),
+    "rsu_pack_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _PI, _i, _vp]),
+    "rsu_pack_conv_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_pack_convT_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "rsu_pack_convT_bwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "rsu_color_adjust_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
+    "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_first_bwd_ws_floats": (_sz, [_i]),
+    "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
+    "rsu_head_ws_floats": (_sz, [_l, _i]),
+    "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
+    "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
+    "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsu_pool_skip_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_weight_ws_floats": (_sz, [_i, _i]),
+    "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_momentum_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _l, _vp]),
+    "rsu_extract_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _l, _l, _vp]),
+    "rsu_overlap_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
+    "rsu_overlap_finish": (_i, [_vp, _vp, _vp, _l, _vp]),
+}
+
+_lib = None
+
+
+class RsuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librsu_hip.so once; raise loudly if it (or any declared symbol) is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsuError("HIP extension missing: %s (build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C road_segmentation_unet_amd/csrc`); there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RsuError("%s failed: rc=%d (hip error %d)" % (what, rc, lib().rsu_last_hip_error()))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    check(getattr(lib(), name)(*args), name)

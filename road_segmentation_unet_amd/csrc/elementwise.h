@@ -1,0 +1,28 @@
+// Launch prototypes of the bandwidth-bound kernels (elementwise.hip).
+#pragma once
+#include "rsu_common.h"
+
+struct PackParams {
+    int nchunks, ntap, ntiles;  // packed dims: [nchunks][ntap][ntiles][64][8]
+    int rows;                   // real output rows (channels)
+    int nseg, seg_c[3];         // K segments (concat sources), real channel counts
+    long s_tap, s_row, s_k;     // source strides (elements)
+    int flip;                   // read source tap (ntap-1-tap)
+};
+
+hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, hipStream_t st);
+hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil, hipStream_t st);
+hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st);
+hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, hipStream_t st);
+hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws, hipStream_t st);
+int ew_colsum_blocks(long npix, int C);
+hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st);
+hipError_t ew_reduce_slabs(const float* slab, float* out, int nsplit, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut, hipStream_t st);
+int ew_head_blocks(long npix, int C);
+hipError_t ew_head(bool train, const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* logits, void* dact, float* dw,
+                   float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st);
+hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, hipStream_t st);
+hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_t st);
+hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
+hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
+hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st);

@@ -1,0 +1,571 @@
+// HBM-bound kernels of the U-Net path: 16-byte (8 x bf16) accesses per lane everywhere, coalesced along
+// the channel axis of NHWC; wave-level shuffles for the per-pixel reductions of the head.
+#include "elementwise.h"
+
+static __device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf_lo(v[i]);
+        f[2 * i + 1] = bf_hi(v[i]);
+    }
+}
+static __device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unet.py:22-23  color_space_adjust
+// ---------------------------------------------------------------------------------------------
+__global__ void k_color_adjust(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                               bf16_t* __restrict__ out16, long npix) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float x0 = x[3 * p] - 0.5f, x1 = x[3 * p + 1] - 0.5f, x2 = x[3 * p + 2] - 0.5f;
+    float f[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = fmaf(x2, w[6 + c], fmaf(x1, w[3 + c], fmaf(x0, w[c], b[c])));
+    f[3] = 0.f;
+    f[4] = x0; f[5] = x1; f[6] = x2; f[7] = 0.f;
+    u32x4* o = (u32x4*)(out16 + 16 * p);
+    o[0] = pack8(f);
+    o[1] = u32x4{0u, 0u, 0u, 0u};
+}
+
+// ---------------------------------------------------------------------------------------------
+// first 3x3 conv (Cin = 3): fp32 VALU, 8 output channels x 4 pixels per thread, weights in LDS
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_conv_first_fwd(const bf16_t* __restrict__ in16, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int N, int H,
+                                                        int W, int Cout, int dil) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ws = (float*)smem;  // [27][Cout]
+    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    const int ncg = Cout >> 3, nxq = (Wo + 3) >> 2;
+    const long total = (long)N * Ho * nxq * ncg;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= total) return;
+    const int cg = (int)(tid % ncg);
+    long r = tid / ncg;
+    const int xq = (int)(r % nxq);
+    r /= nxq;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    const int ox0 = xq * 4, co = cg * 8;
+    float acc[4][8];
+#pragma unroll
+    for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[px][i] = bias ? bias[co + i] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const bf16_t* row = in16 + ((long)(n * H + oy + ky * dil) * W) * 16;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float wv[3][8];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wv[ci][i] = ws[((ky * 3 + kx) * 3 + ci) * Cout + co + i];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                int ix = ox0 + px + kx * dil;
+                if (ix > W - 1) ix = W - 1;  // only reached by pixels that are not stored
+                const u32x2 v = *(const u32x2*)(row + (long)ix * 16);
+                const float x0 = bf_lo(v[0]), x1 = bf_hi(v[0]), x2 = bf_lo(v[1]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[px][i] = fmaf(x2, wv[2][i], fmaf(x1, wv[1][i], fmaf(x0, wv[0][i], acc[px][i])));
+            }
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+        if (ox0 + px >= Wo) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[px][i] = fmaxf(acc[px][i], 0.f);
+        *(u32x4*)(y + ((long)(n * Ho + oy) * Wo + ox0 + px) * Cout + co) = pack8(acc[px]);
+    }
+}
+
+// rows 0..2 / 4..6 of the [9][16][Cout] narrow weight-gradient block -> dw1 / gxc [9][3][Cout]
+__global__ void k_scatter_first_grads(const float* __restrict__ tmp, float* __restrict__ dw1, float* __restrict__ gxc, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 27 * Cout) return;
+    const int co = i % Cout, r = i / Cout, ci = r % 3, tap = r / 3;
+    dw1[i] = tmp[((long)tap * 16 + ci) * Cout + co];
+    if (gxc) gxc[i] = tmp[((long)tap * 16 + 4 + ci) * Cout + co];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2 max pool forward
+// ---------------------------------------------------------------------------------------------
+__global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C) {
+    const int Ho = H >> 1, Wo = W >> 1, ncg = C >> 3;
+    const long total = (long)N * Ho * Wo * ncg;
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(tid % ncg);
+        long r = tid / ncg;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        const bf16_t* p = x + ((long)(n * H + 2 * oy) * W + 2 * ox) * C + cg * 8;
+        float a[8], b[8], c[8], d[8];
+        unpack8(*(const u32x4*)p, a);
+        unpack8(*(const u32x4*)(p + C), b);
+        unpack8(*(const u32x4*)(p + (long)W * C), c);
+        unpack8(*(const u32x4*)(p + (long)W * C + C), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], d[i]));
+        *(u32x4*)(y + ((long)(n * Ho + oy) * Wo + ox) * C + cg * 8) = pack8(a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient junction at an encoder output: MaxPoolGrad + zero-padded skip gradient + ReluGrad.
+// One thread = 8 channels of one 2x2 window.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const bf16_t* __restrict__ dpool,
+                                     const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dz, int N, int H, int W, int C,
+                                     int Hs, int Ws) {
+    const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1, ncg = C >> 3;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int oy0 = (H - Hs) / 2, ox0 = (W - Ws) / 2;
+    const long total = (long)N * Hw * Ww * ncg;
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(tid % ncg);
+        long r = tid / ncg;
+        const int wx = (int)(r % Ww);
+        r /= Ww;
+        const int wy = (int)(r % Hw), n = (int)(r / Hw);
+        float v[4][8], g[4][8];
+        bool inb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
+            inb[k] = (yy < H) && (xx < W);
+            if (inb[k]) {
+                unpack8(*(const u32x4*)(yact + ((long)(n * H + yy) * W + xx) * C + cg * 8), v[k]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+            }
+            const int sy = yy - oy0, sx = xx - ox0;
+            if (dskip && inb[k] && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
+                unpack8(*(const u32x4*)(dskip + ((long)(n * Hs + sy) * Ws + sx) * C + cg * 8), g[k]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[k][i] = 0.f;
+            }
+        }
+        if (dpool && wy < Hp && wx < Wp) {
+            float dp[8];
+            unpack8(*(const u32x4*)(dpool + ((long)(n * Hp + wy) * Wp + wx) * C + cg * 8), dp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int best = 0;
+                float m = v[0][i];
+                if (v[1][i] > m) { m = v[1][i]; best = 1; }
+                if (v[2][i] > m) { m = v[2][i]; best = 2; }
+                if (v[3][i] > m) { m = v[3][i]; best = 3; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k][i] += (best == k) ? dp[i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!inb[k]) continue;
+            const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[k][i] = v[k][i] > 0.f ? g[k][i] : 0.f;
+            *(u32x4*)(dz + ((long)(n * H + yy) * W + xx) * C + cg * 8) = pack8(g[k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BiasAddGrad: per-channel sums over pixels, two deterministic stages
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_colsum_partial(const bf16_t* __restrict__ dz, float* __restrict__ partial, long npix, int C) {
+    __shared__ float red[256 * 8];
+    const int ncg = C >> 3;
+    const int lanes_p = 256 / ncg;  // pixel lanes per block (ncg divides 256)
+    const int cg = threadIdx.x % ncg, pl = threadIdx.x / ncg;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pl < lanes_p) {
+        for (long p = (long)blockIdx.x * lanes_p + pl; p < npix; p += (long)gridDim.x * lanes_p) {
+            float f[8];
+            unpack8(*(const u32x4*)(dz + p * C + cg * 8), f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += f[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c >> 3, i = c & 7;
+        float t = 0.f;
+        for (int q = 0; q < lanes_p; ++q) t += red[(q * ncg + g) * 8 + i];
+        partial[(long)blockIdx.x * C + c] = t;
+    }
+}
+// C may exceed 256: handled by launching with blockDim = 256 and looping channels in the second stage only;
+// the first stage requires C <= 2048 and (C/8) | 256, checked by the host.
+__global__ void k_colsum_final(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += partial[(long)b * C + c];
+    out[c] = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K slab reduction: out[row][col] = sum_z slab[z][row][col] for the rows of one source
+// rows are (tap, cs) pairs: row index -> tap*CsOut + cs_off + cs
+// ---------------------------------------------------------------------------------------------
+__global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntap, int CsOut,
+                               int cs_off, int cs_cnt, int CfOut) {
+    const int cf4 = CfOut >> 2;
+    const long total = (long)ntap * cs_cnt * cf4;
+    const long slab_elems = (long)ntap * CsOut * CfOut;
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(tid % cf4);
+        long r = tid / cf4;
+        const int cs = (int)(r % cs_cnt), tap = (int)(r / cs_cnt);
+        const long e = ((long)tap * CsOut + cs_off + cs) * CfOut + c4 * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; ++z) t += *(const f32x4*)(slab + z * slab_elems + e);
+        *(f32x4*)(out + e) = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: 1x1 conv (C -> 2) + softmax[...,1] (+ mean CE loss and its backward)
+// LP = C/8 lanes per pixel, partial logits reduced with wave shuffles
+// ---------------------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ void __launch_bounds__(256) k_head(const bf16_t* __restrict__ act, const float* __restrict__ w, const float* __restrict__ b,
+                                              const int64_t* __restrict__ labels, float* __restrict__ prob, float* __restrict__ logits,
+                                              bf16_t* __restrict__ dact, float* __restrict__ partial, long npix, int C, float inv_count) {
+    const int LP = C >> 3;
+    const int sub = threadIdx.x % LP;
+    const int ppb = 256 / LP;  // pixels per block iteration
+    float w0[8], w1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w0[i] = w[(sub * 8 + i) * 2];
+        w1[i] = w[(sub * 8 + i) * 2 + 1];
+    }
+    const float b0 = b[0], b1 = b[1];
+    float gw0[8], gw1[8], gb0 = 0.f, gb1 = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gw0[i] = gw1[i] = 0.f;
+    const long niter = (npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
+    for (long it = 0; it < niter; ++it) {
+        const long p = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / LP;
+        const bool ok = p < npix;
+        float a[8];
+        if (ok) {
+            unpack8(*(const u32x4*)(act + p * C + sub * 8), a);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = 0.f;
+        }
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            l0 = fmaf(a[i], w0[i], l0);
+            l1 = fmaf(a[i], w1[i], l1);
+        }
+        for (int o = 1; o < LP; o <<= 1) {
+            l0 += __shfl_xor(l0, o);
+            l1 += __shfl_xor(l1, o);
+        }
+        l0 += b0;
+        l1 += b1;
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float s = e0 + e1;
+        const float p1 = e1 / s, p0 = e0 / s;
+        if (ok && sub == 0) {
+            prob[p] = p1;
+            if (logits) {
+                logits[2 * p] = l0;
+                logits[2 * p + 1] = l1;
+            }
+        }
+        if (TRAIN) {
+            if (ok) {
+                const int lab = (int)labels[p];
+                const float d0 = (p0 - (lab == 0 ? 1.f : 0.f)) * inv_count;
+                const float d1 = (p1 - (lab == 1 ? 1.f : 0.f)) * inv_count;
+                float da[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    gw0[i] = fmaf(a[i], d0, gw0[i]);
+                    gw1[i] = fmaf(a[i], d1, gw1[i]);
+                    da[i] = a[i] > 0.f ? fmaf(d0, w0[i], d1 * w1[i]) : 0.f;
+                }
+                *(u32x4*)(dact + p * C + sub * 8) = pack8(da);
+                if (sub == 0) {
+                    gb0 += d0;
+                    gb1 += d1;
+                    lsum += -((lab ? l1 : l0) - m - logf(s));
+                }
+            }
+        }
+    }
+    if (TRAIN) {
+        // block reduce: threads with equal `sub` hold partials for the same 8 channels
+        __shared__ float red[256 * 19];
+        float* my = red + threadIdx.x * 19;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            my[i] = gw0[i];
+            my[8 + i] = gw1[i];
+        }
+        my[16] = gb0; my[17] = gb1; my[18] = lsum;
+        __syncthreads();
+        const int nout = 2 * C + 3;  // [C][2] dw, db[2], loss
+        for (int o = threadIdx.x; o < nout; o += 256) {
+            float t = 0.f;
+            if (o < 2 * C) {
+                const int c = o >> 1, k = o & 1, sg = c >> 3, i = c & 7;
+                for (int q = 0; q < ppb; ++q) t += red[(q * LP + sg) * 19 + k * 8 + i];
+            } else {
+                const int j = 16 + (o - 2 * C);
+                for (int q = 0; q < ppb; ++q) t += red[(q * LP) * 19 + j];
+            }
+            partial[(long)blockIdx.x * nout + o] = t;
+        }
+    }
+}
+template __global__ void k_head<true>(const bf16_t*, const float*, const float*, const int64_t*, float*, float*, bf16_t*, float*, long, int, float);
+template __global__ void k_head<false>(const bf16_t*, const float*, const float*, const int64_t*, float*, float*, bf16_t*, float*, long, int, float);
+
+__global__ void k_head_final(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss_sum,
+                             int nblk, int C) {
+    const int nout = 2 * C + 3;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nout) return;
+    float t = 0.f;
+    for (int bk = 0; bk < nblk; ++bk) t += partial[(long)bk * nout + o];
+    if (o < 2 * C) dw[o] = t;
+    else if (o < 2 * C + 2) db[o - 2 * C] = t;
+    else loss_sum[0] += t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// momentum SGD (tf_aerial_images.py:116-121)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_momentum(float* __restrict__ w, float* __restrict__ acc, const float* __restrict__ g, float lr, float mu, float gscale, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 a = ((f32x4*)acc)[i], gv = ((const f32x4*)g)[i], wv = ((f32x4*)w)[i];
+        a = mu * a + gscale * gv;
+        wv -= lr * a;
+        ((f32x4*)acc)[i] = a;
+        ((f32x4*)w)[i] = wv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float a = mu * acc[i] + gscale * g[i];
+        acc[i] = a;
+        w[i] -= lr * a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing into MFMA fragment order: packed[chunk][tap][tile][lane][8]
+//   element (chunk, tap, tile T, lane, j): row rho = lane&15 of tile T, k = chunk*32 + 8*(lane>>4) + j
+//   tile pair P = T/2, t = T%2: output channel of the row = 32P + 8*(rho>>2) + 4t + (rho&3)
+//   k runs over the 32-padded concatenation of the K segments (concat sources)
+// value = src[tapmap(tap)*s_tap + row*s_row + kreal*s_k]
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack(const float* __restrict__ src, bf16_t* __restrict__ dst, PackParams pp) {
+    const long total = (long)pp.nchunks * pp.ntap * pp.ntiles * 512;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int T = (int)(r % pp.ntiles);
+        r /= pp.ntiles;
+        const int tap = (int)(r % pp.ntap), chunk = (int)(r / pp.ntap);
+        const int rho = lane & 15;
+        const int row = 32 * (T >> 1) + 8 * (rho >> 2) + 4 * (T & 1) + (rho & 3);
+        int k = chunk * 32 + 8 * (lane >> 4) + j;
+        // locate the K segment
+        int kreal = -1, base_pad = 0, base_real = 0;
+        for (int s = 0; s < pp.nseg; ++s) {
+            const int cpad = (pp.seg_c[s] + 31) & ~31;
+            if (k >= base_pad && k < base_pad + cpad) {
+                const int c = k - base_pad;
+                if (c < pp.seg_c[s]) kreal = base_real + c;
+            }
+            base_pad += cpad;
+            base_real += pp.seg_c[s];
+        }
+        float v = 0.f;
+        if (kreal >= 0 && row < pp.rows) {
+            const int tsrc = pp.flip ? (pp.ntap - 1 - tap) : tap;
+            v = src[(long)tsrc * pp.s_tap + (long)row * pp.s_row + (long)kreal * pp.s_k];
+        }
+        dst[e] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tiler: mirror_border + extract_patches fused (images.py:269-281,35-85), overlap-add (images.py:131-164)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_extract_tiles(const float* __restrict__ imgs, float* __restrict__ tiles, int H, int S, int P, int stride,
+                                int pps, long t0, long ntiles) {
+    const int off = (S - P) / 2;
+    const long total = ntiles * S * S;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % S);
+        long r = e / S;
+        const int yy = (int)(r % S);
+        const long tl = r / S;
+        const long tg = t0 + tl;
+        const int img = (int)(tg / (pps * pps)), tt = (int)(tg % (pps * pps));
+        const int x0 = (tt / pps) * stride, y0 = (tt % pps) * stride;  // x outer, y inner
+        int sy = y0 + yy - off, sx = x0 + x - off;                       // coordinates in the un-padded image
+        sy = sy < 0 ? -sy - 1 : (sy >= H ? 2 * H - 1 - sy : sy);         // np.pad 'symmetric'
+        sx = sx < 0 ? -sx - 1 : (sx >= H ? 2 * H - 1 - sx : sx);
+        const float* s = imgs + ((long)(img * H + sy) * H + sx) * 3;
+        float* d = tiles + e * 3;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    }
+}
+
+// gather form (deterministic, no atomics): one thread per output pixel sums, in increasing tile index, the tiles of
+// [t0, t0+ntiles) that cover it; the in-call sum is kept in double and added to the float accumulator once.
+__global__ void k_overlap_add(const float* __restrict__ prob, float* __restrict__ acc, float* __restrict__ hits, int nimg, int H, int P,
+                              int stride, int pps, long t0, long ntiles) {
+    const long total = (long)nimg * H * H;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % H);
+        long r = e / H;
+        const int y = (int)(r % H), img = (int)(r / H);
+        int xi_lo = (x - P + stride) / stride; if (x - P + 1 <= 0) xi_lo = 0;
+        int yi_lo = (y - P + stride) / stride; if (y - P + 1 <= 0) yi_lo = 0;
+        int xi_hi = x / stride; if (xi_hi > pps - 1) xi_hi = pps - 1;
+        int yi_hi = y / stride; if (yi_hi > pps - 1) yi_hi = pps - 1;
+        double s = 0.0;
+        int cnt = 0;
+        for (int xi = xi_lo; xi <= xi_hi; ++xi)
+            for (int yi = yi_lo; yi <= yi_hi; ++yi) {
+                const long t = (long)img * pps * pps + (long)xi * pps + yi;
+                if (t < t0 || t >= t0 + ntiles) continue;
+                s += (double)prob[((t - t0) * P + (y - yi * stride)) * P + (x - xi * stride)];
+                ++cnt;
+            }
+        if (cnt) {
+            acc[e] += (float)s;
+            hits[e] += (float)cnt;
+        }
+    }
+}
+
+__global__ void k_overlap_finish(const float* __restrict__ acc, const float* __restrict__ hits, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = acc[i] / hits[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(long total, int block, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, hipStream_t st) {
+    hipLaunchKernelGGL(k_color_adjust, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, w, b, (bf16_t*)out16, npix);
+    return hipGetLastError();
+}
+hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil,
+                             hipStream_t st) {
+    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    const long total = (long)N * Ho * ((Wo + 3) / 4) * (Cout / 8);
+    hipLaunchKernelGGL(k_conv_first_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 27 * Cout * sizeof(float), st,
+                       (const bf16_t*)in16, w, b, (bf16_t*)y, N, H, W, Cout, dil);
+    return hipGetLastError();
+}
+hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st) {
+    hipLaunchKernelGGL(k_scatter_first_grads, dim3((27 * Cout + 255) / 256), dim3(256), 0, st, tmp, dw1, gxc, Cout);
+    return hipGetLastError();
+}
+hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, hipStream_t st) {
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C);
+    return hipGetLastError();
+}
+hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs,
+                                 int Ws, hipStream_t st) {
+    const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    hipLaunchKernelGGL(k_pool_skip_relu_bwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)yact, (const bf16_t*)dpool,
+                       (const bf16_t*)dskip, (bf16_t*)dz, N, H, W, C, Hs, Ws);
+    return hipGetLastError();
+}
+int ew_colsum_blocks(long npix, int C) {
+    const int lanes_p = 256 / (C / 8);
+    long nb = (npix + (long)lanes_p * 64 - 1) / ((long)lanes_p * 64);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st) {
+    const int nb = ew_colsum_blocks(npix, C);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, (const bf16_t*)dz, ws, npix, C);
+    hipLaunchKernelGGL(k_colsum_final, dim3((C + 255) / 256), dim3(256), 0, st, ws, db, nb, C);
+    return hipGetLastError();
+}
+hipError_t ew_reduce_slabs(const float* slab, float* out, int nsplit, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut,
+                           hipStream_t st) {
+    const long total = (long)ntap * cs_cnt * (CfOut / 4);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off, cs_cnt, CfOut);
+    return hipGetLastError();
+}
+int ew_head_blocks(long npix, int C) {
+    const int ppb = 256 / (C / 8);
+    long nb = (npix + (long)ppb * 8 - 1) / ((long)ppb * 8);
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+hipError_t ew_head(bool train, const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* logits, void* dact,
+                   float* dw, float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st) {
+    const int nb = ew_head_blocks(npix, C);
+    if (train) {
+        hipLaunchKernelGGL(k_head<true>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, labels, prob, logits, (bf16_t*)dact, ws, npix, C, inv_count);
+        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 255) / 256), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
+    } else {
+        hipLaunchKernelGGL(k_head<false>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, nullptr, prob, logits, nullptr, nullptr, npix, C, 0.f);
+    }
+    return hipGetLastError();
+}
+hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_momentum, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, w, acc, g, lr, mu, gscale, n);
+    return hipGetLastError();
+}
+hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_t st) {
+    const long total = (long)pp.nchunks * pp.ntap * pp.ntiles * 512;
+    hipLaunchKernelGGL(k_pack, dim3(grid_for(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, pp);
+    return hipGetLastError();
+}
+hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st) {
+    hipLaunchKernelGGL(k_extract_tiles, dim3(grid_for(ntiles * S * S, 256)), dim3(256), 0, st, imgs, tiles, H, S, P, stride, pps, t0, ntiles);
+    return hipGetLastError();
+}
+hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st) {
+    hipLaunchKernelGGL(k_overlap_add, dim3(grid_for((long)nimg * H * H, 256)), dim3(256), 0, st, prob, acc, hits, nimg, H, P, stride, pps, t0, ntiles);
+    return hipGetLastError();
+}
+hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st) {
+    hipLaunchKernelGGL(k_overlap_finish, dim3(grid_for(n, 256)), dim3(256), 0, st, acc, hits, out, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,69 @@
+// Parameter blocks + launch prototypes of the two MFMA implicit-GEMM kernels.
+#pragma once
+#include "rsu_common.h"
+
+struct IgSrc {
+    const bf16_t* ptr;
+    int H, W, C;  // tensor dims
+    int oy, ox;   // window origin
+};
+
+// ---------------------------------------------------------------------------------------------
+// igemm_fwd: out[n][o][co] = epi( sum_tap sum_k  in[n][o*stride + tap*dil - pad][k] * A[tap][co][k] )
+//   conv3x3 forward      : 9 taps, stride 1, pad 0
+//   conv3x3 backward-data: 9 taps (flipped in the packing), stride 1, pad 2*dil, input = dz
+//   convT 2x2 forward    : 1 tap, blockIdx.y = a*2+b selects the matrix and the output phase
+//   convT 2x2 bwd-data   : 4 taps (2x2), stride 2, dil 1, input = dy
+// ---------------------------------------------------------------------------------------------
+struct IgFwdParams {
+    IgSrc src[3];
+    int nsrc;
+    int nchunk[3];        // 32-channel chunks per source (ceil(C/32))
+    const bf16_t* wp;     // packed A: [chunk][tap][tile16][lane][8]
+    long wp_y_stride;     // elements between blockIdx.y slices of wp (convT forward), else 0
+    int ntiles_w;         // 16-row tiles per (chunk, tap) in wp
+    int tile_off;         // first tile of this launch's output channel 0
+    const float* bias;    // [Cout] or null
+    bf16_t* out;          // [N][oH][oW][outC]
+    const bf16_t* mask_src;  // same geometry as out, or null
+    const void* zero_page;   // >= 64 zero bytes
+    int N, Hin, Win;      // logical input window
+    int Ho, Wo;           // output pixel grid of the GEMM (before output scatter)
+    int Cout;             // channels produced (<= ncob*TN), multiple of 8
+    int outC;             // channel pitch of out
+    int dil, stride, pad;
+    int oH, oW, ostride;  // out tensor geometry; out pixel = o*ostride + (blockIdx.y phase)
+    int relu, accumulate;
+    int ncob;
+    TileGeo g;
+};
+
+// config ids (see igemm_fwd.hip for the tile shapes)
+enum { IGF_CFG_64x256 = 0, IGF_CFG_128x256 = 1, IGF_CFG_128x128 = 2, IGF_CFG_128x64 = 3, IGF_CFG_64x128 = 4, IGF_NCFG = 5 };
+struct IgFwdCfgInfo { int TN, TM, threads; };
+IgFwdCfgInfo igemm_fwd_cfg_info(int cfg);
+size_t igemm_fwd_lds_bytes(int cfg, int ntap, int npix_max);
+// ntap in {1,4,9}
+hipError_t igemm_fwd_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// igemm_wgrad: slab[z][tap][cs_off+cs][cf] = sum_{pix in split z} S[n][pix*stride + tap*dil][cs] * F[n][pix][cf]
+//   conv3x3 backward-weight : F = dz (cf = co), S = layer input (cs = ci), 9 taps
+//   convT 2x2 backward-weight: F = x (cf = ci), S = dy (cs = co), 4 taps, stride 2
+// ---------------------------------------------------------------------------------------------
+struct IgWgradParams {
+    const bf16_t* F;
+    int Hf, Wf, Cf;     // F tensor [N][Hf][Wf][Cf]; the pixel grid of the reduction
+    IgSrc S;
+    float* slab;        // [nsplit][ntap][CsOut][CfOut]
+    int CsOut, CfOut, cs_off;
+    const void* zero_page;
+    int N, dil, stride;
+    int nsplit, ntiles_total;
+    TileGeo g;          // TM of this geometry = pixels per reduction tile
+};
+enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_NCFG = 2 };
+size_t igemm_wgrad_lds_bytes(int cfg, int npix_max);
+int igemm_wgrad_tmk(int cfg);
+hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,
+                              hipStream_t st);

@@ -1,0 +1,222 @@
+// igemm_wgrad: weight-gradient implicit GEMM, reduction over pixels, on v_mfma_f32_16x16x32_bf16.
+//
+//   slab[z][tap][cs][cf] = sum over the pixels of split z of  S[pix*stride + tap*dil][cs] * F[pix][cf]
+//
+// Both operands are channel-contiguous (NHWC) in memory but the MFMA wants 8 consecutive REDUCTION
+// indices (pixels) per lane, so both are staged pixel-major in LDS and read with the gfx950 transposed
+// LDS read ds_read_b64_tr_b16 (4 pixel rows x 16 channels -> channel-per-lane, 4 pixels per lane).
+// The reduction order inside a 32-pixel MFMA step is permuted identically for both operands
+// (lane group g takes pixels 4g..4g+3 and 16+4g..16+4g+3), which makes each 32-lane half of a tr-read
+// touch 8 consecutive pixels: with 128-byte pixels and the 32-byte-block XOR swizzle (pixel>>1)&3 that
+// is bank-conflict free (tools/lds_bank_sim.py).
+// The S halo tile is staged once per pixel tile and re-used by all taps (tap = pixel offset), F once.
+// Each workgroup owns a 64(cf) x CSB(cs) block for ALL taps (9*4 = 36 accumulator tiles per wave at the
+// default shape), walks the pixel tiles of its split with double-buffered LDS-DMA staging, and writes one
+// fp32 slab; reduce_slabs (elementwise.hip) sums the splits deterministically.
+#include "igemm.h"
+
+template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK>
+__global__ void __launch_bounds__(WCF* WCS * 64) igemm_wgrad_kernel(const IgWgradParams p) {
+    constexpr int NW = WCF * WCS;
+    constexpr int CFB = WCF * CFT * 16;  // must be 64
+    constexpr int CSB = WCS * CST * 16;  // 64 or 16
+    constexpr int KH = NTAP / KW;
+    constexpr int SPITCH = CSB * 2;      // bytes per S pixel in LDS
+    constexpr int LPP = CSB / 8;         // lanes (16-B pieces) per S pixel
+    constexpr int PPP = 64 / LPP;        // S pixels per DMA piece
+    constexpr int FBUF = TMK * 128;
+    static_assert(CFB == 64, "F block is 64 channels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+    const int SBUF = p.g.npix_max * SPITCH;
+    const int s_base = 2 * FBUF;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wcf = wave / WCS, wcs = wave % WCS;
+    const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
+    const int cfb = blockIdx.x, csb = blockIdx.y, z = blockIdx.z;
+    const int SW = p.g.SW, CW = p.g.CW;
+    const int tpi = p.g.nstrips * p.g.tiles_per_strip;
+    const int Hs = (p.Hf - 1) * p.stride + (KH - 1) * p.dil + 1;  // S window extent
+    const int Ws = (p.Wf - 1) * p.stride + (KW - 1) * p.dil + 1;
+
+    f32x4 acc[NTAP][CFT][CST];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int a = 0; a < CFT; ++a)
+#pragma unroll
+            for (int b = 0; b < CST; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Tile { int n, x0, sw, m0, y_first, npix; };
+    auto decode = [&](int tile) {
+        Tile T;
+        T.n = tile / tpi;
+        int r = tile - T.n * tpi;
+        const int strip = r / p.g.tiles_per_strip;
+        const int mt = r - strip * p.g.tiles_per_strip;
+        T.x0 = strip * SW;
+        T.sw = min(SW, p.Wf - T.x0);
+        T.m0 = mt * TMK;
+        T.y_first = T.m0 / SW;
+        int y_last = (T.m0 + TMK - 1) / SW;
+        if (y_last > p.Hf - 1) y_last = p.Hf - 1;
+        const int R = (y_last - T.y_first) * p.stride + (KH - 1) * p.dil + 1;
+        T.npix = R * CW;
+        return T;
+    };
+    auto issue = [&](const Tile& T, int buf) {
+        // F tile: TMK pixels x 64 channels, 8 pixels per DMA piece
+        for (int j = wave; j < TMK / 8; j += NW) {
+            const int ml = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
+            const int m = T.m0 + ml;
+            const int y = div_magic(m, p.g.inv_SW);
+            const int tx = m - y * SW;
+            const int ch = cfb * 64 + c * 8;
+            const bool ok = (y < p.Hf) && (tx < T.sw) && (ch < p.Cf);
+            const bf16_t* src = ok ? p.F + ((long)(T.n * p.Hf + y) * p.Wf + T.x0 + tx) * p.Cf + ch : (const bf16_t*)p.zero_page;
+            dma16(src, (void*)(lds + buf * FBUF + j * 1024));
+        }
+        // S halo tile
+        const int npieces = (T.npix + PPP - 1) / PPP;
+        const int iy0 = T.y_first * p.stride, ix0 = T.x0 * p.stride;
+        for (int j = wave; j < npieces; j += NW) {
+            const int hp = j * PPP + lane / LPP;
+            const int pc = lane % LPP;
+            const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
+            const int rr = div_magic(hp, p.g.inv_CW);
+            const int cc = hp - rr * CW;
+            const int iy = iy0 + rr, ix = ix0 + cc;
+            const int ch = csb * CSB + c * 8;
+            const bool ok = (hp < T.npix) && (iy < Hs) && (ix < Ws) && (ch < p.S.C);
+            const bf16_t* src =
+                ok ? p.S.ptr + ((long)(T.n * p.S.H + iy + p.S.oy) * p.S.W + ix + p.S.ox) * p.S.C + ch : (const bf16_t*)p.zero_page;
+            dma16(src, (void*)(lds + s_base + buf * SBUF + j * 1024));
+        }
+    };
+
+    int tile = z;
+    Tile cur = decode(tile);
+    issue(cur, 0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < p.ntiles_total; tile += p.nsplit) {
+        const int nxt = tile + p.nsplit;
+        Tile nt = cur;
+        if (nxt < p.ntiles_total) {
+            nt = decode(nxt);
+            issue(nt, buf ^ 1);
+        }
+        const int fb = buf * FBUF, sb = s_base + buf * SBUF;
+#pragma unroll
+        for (int ks = 0; ks < TMK / 32; ++ks) {
+            // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
+            bf16x8 fa[CFT];
+            int hps[2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int ml = ks * 32 + rd * 16 + 4 * g4 + q4;
+                const int m = cur.m0 + ml;
+                const int y = div_magic(m, p.g.inv_SW);
+                const int tx = m - y * SW;
+                const bool valid = (y < p.Hf) && (tx < cur.sw);
+                hps[rd] = valid ? ((y - cur.y_first) * p.stride * CW + tx * p.stride) : 0;
+#pragma unroll
+                for (int ct = 0; ct < CFT; ++ct) {
+                    const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
+                    const int off = ml * 128 + ((((ch >> 4) ^ ((ml >> 1) & 3))) << 5) + (ch & 15) * 2;
+                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds + fb + off));
+                    fa[ct][rd * 4 + 0] = v[0];
+                    fa[ct][rd * 4 + 1] = v[1];
+                    fa[ct][rd * 4 + 2] = v[2];
+                    fa[ct][rd * 4 + 3] = v[3];
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap) {
+                const int ky = tap / KW, kx = tap - ky * KW;
+                const int toff = (ky * CW + kx) * p.dil;
+                bf16x8 sbv[CST];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int hp = hps[rd] + toff;
+#pragma unroll
+                    for (int st = 0; st < CST; ++st) {
+                        const int ch = (wcs * CST + st) * 16 + 4 * p4;
+                        const int off = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
+                                                   : (hp * SPITCH + ch * 2);
+                        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) bf16x4*)(lds + sb + off));
+                        sbv[st][rd * 4 + 0] = v[0];
+                        sbv[st][rd * 4 + 1] = v[1];
+                        sbv[st][rd * 4 + 2] = v[2];
+                        sbv[st][rd * 4 + 3] = v[3];
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < CFT; ++ct)
+#pragma unroll
+                    for (int st = 0; st < CST; ++st)
+                        acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], sbv[st], acc[tap][ct][st], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        cur = nt;
+        buf ^= 1;
+    }
+
+    // ---- write this split's slab: D rows = cf (4 consecutive per lane), cols = cs
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+        for (int st = 0; st < CST; ++st) {
+            const int cs = csb * CSB + (wcs * CST + st) * 16 + l15;
+            if (cs >= p.S.C) continue;
+#pragma unroll
+            for (int ct = 0; ct < CFT; ++ct) {
+                const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
+                if (cf >= p.Cf) continue;
+                float* dst = p.slab + (((long)z * NTAP + tap) * p.CsOut + p.cs_off + cs) * p.CfOut + cf;
+                *(f32x4*)dst = acc[tap][ct][st];
+            }
+        }
+}
+
+template <int CFG> struct WgCfg;
+template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 2, WCS = 2, CFT = 2, CST = 2, TMK = 128; };
+template <> struct WgCfg<IGW_CFG_64x16> { static constexpr int WCF = 4, WCS = 1, CFT = 1, CST = 1, TMK = 128; };
+
+int igemm_wgrad_tmk(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::TMK : WgCfg<IGW_CFG_64x16>::TMK; }
+
+size_t igemm_wgrad_lds_bytes(int cfg, int npix_max) {
+    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
+    return (size_t)2 * igemm_wgrad_tmk(cfg) * 128 + (size_t)2 * npix_max * csb * 2;
+}
+
+template <int CFG, int NTAP, int KW>
+static hipError_t wlaunch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    using C = WgCfg<CFG>;
+    auto kern = igemm_wgrad_kernel<C::WCF, C::WCS, C::CFT, C::CST, NTAP, KW, C::TMK>;
+    const size_t lds = igemm_wgrad_lds_bytes(CFG, p.g.npix_max);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(C::WCF * C::WCS * 64), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    if (cfg == IGW_CFG_64x64) {
+        if (ntap == 9) return wlaunch_one<IGW_CFG_64x64, 9, 3>(p, gx, gy, gz, st);
+        if (ntap == 4) return wlaunch_one<IGW_CFG_64x64, 4, 2>(p, gx, gy, gz, st);
+    } else if (cfg == IGW_CFG_64x16) {
+        if (ntap == 9) return wlaunch_one<IGW_CFG_64x16, 9, 3>(p, gx, gy, gz, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,434 @@
+// extern "C" entry points of librsu_hip.so (declared in include/rsu.h): argument checks, tile planning,
+// kernel-configuration choice and launches. No torch types, no hidden allocations: every buffer is the
+// caller's; the only library-owned device memory is a 4-KiB page of zeros used for out-of-window reads.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/rsu.h"
+#include "elementwise.h"
+#include "igemm.h"
+
+static std::atomic<int> g_last_hip_error{0};
+static void rsu_set_hip_error(int e) { g_last_hip_error.store(e); }
+
+__device__ uint4 g_zero_page_dev[256];  // 4 KiB, zero-initialised
+
+static const void* zero_page() {
+    static void* ptr = nullptr;
+    if (!ptr) {
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_dev)) != hipSuccess) return nullptr;
+        ptr = q;
+    }
+    return ptr;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+static inline unsigned magic32(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+static inline int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+extern "C" const char* rsu_version(void) { return "rsu-hip 0.1 (gfx950)"; }
+extern "C" int rsu_last_hip_error(void) { return g_last_hip_error.load(); }
+
+extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input_size) {
+    // unet.py:100-115: (L-1) x { assert even; o = (o+4)/2 }, (L-1) x { o = (o+4)*2 }, +4
+    if (!input_size || num_layers < 1 || output_size < 1) return RSU_EINVAL;
+    long o2 = output_size;  // exact in integers: while o stays even the reference's float maths is integral
+    for (int i = 0; i < num_layers - 1; ++i) {
+        if (o2 % 2 != 0) return RSU_EINVAL;
+        o2 = (o2 + 4) / 2;
+    }
+    for (int i = 0; i < num_layers - 1; ++i) o2 = (o2 + 4) * 2;
+    *input_size = (int)(o2 + 4);
+    return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile planning
+// ---------------------------------------------------------------------------------------------
+// Choose the strip width for a Ho x Wo pixel grid cut into TM-pixel tiles; npix_cap = LDS pixels available.
+static bool plan_geo(TileGeo& best, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap) {
+    if (Ho < 1 || Wo < 2) return false;
+    int cands[6];
+    int nc = 0;
+    if (Wo <= 96) cands[nc++] = Wo;
+    cands[nc++] = 64;
+    cands[nc++] = 32;
+    cands[nc++] = 16;
+    cands[nc++] = 8;
+    double best_cost = 1e30;
+    bool found = false;
+    for (int i = 0; i < nc; ++i) {
+        const int SW = cands[i];
+        if (SW > Wo && SW != cands[0]) continue;
+        if (SW < 2) continue;
+        TileGeo g;
+        g.SW = SW;
+        g.nstrips = cdiv(Wo, SW);
+        g.tiles_per_strip = cdiv(Ho * SW, TM);
+        int rows = (TM % SW == 0) ? TM / SW : TM / SW + 2;
+        if (rows > Ho) rows = Ho;
+        const int R = (rows - 1) * stride + (kh - 1) * dil + 1;
+        g.CW = rup((SW - 1) * stride + (kw - 1) * dil + 1, 8);
+        g.npix_max = rup(R * g.CW, 32);
+        if (g.npix_max > npix_cap) continue;
+        g.inv_SW = magic32(SW);
+        g.inv_CW = magic32(g.CW);
+        const double waste = (double)g.nstrips * g.tiles_per_strip * TM / ((double)Ho * Wo);
+        const double halo = (double)g.npix_max / TM;
+        const double cost = waste * (1.0 + 0.05 * halo);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = g;
+            found = true;
+        }
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+static int kpad_total(const int* seg_c, int nseg) {
+    int k = 0;
+    for (int i = 0; i < nseg; ++i) k += rup(seg_c[i], 32);
+    return k;
+}
+extern "C" size_t rsu_packed_bytes(int taps, int rows, const int* seg_c, int nseg) {
+    return (size_t)taps * kpad_total(seg_c, nseg) * rup(rows, 128) * 2;
+}
+static int do_pack(const float* src, void* dst, int ntap, int rows, const int* seg_c, int nseg, long s_tap, long s_row, long s_k,
+                   int flip, hipStream_t st) {
+    if (!src || !dst || nseg < 1 || nseg > 3) return RSU_EINVAL;
+    PackParams pp;
+    pp.nchunks = kpad_total(seg_c, nseg) / 32;
+    pp.ntap = ntap;
+    pp.ntiles = rup(rows, 128) / 16;
+    pp.rows = rows;
+    pp.nseg = nseg;
+    for (int i = 0; i < 3; ++i) pp.seg_c[i] = i < nseg ? seg_c[i] : 0;
+    pp.s_tap = s_tap;
+    pp.s_row = s_row;
+    pp.s_k = s_k;
+    pp.flip = flip;
+    HIP_CHECK_RET(ew_pack(src, dst, pp, st));
+    return RSU_OK;
+}
+extern "C" int rsu_pack_conv_fwd(const float* w, void* packed, int k, int Cin, int Cout, const int* seg_c, int nseg, rsu_stream_t stream) {
+    int one[1] = {Cin};
+    if (!seg_c) { seg_c = one; nseg = 1; }
+    int sum = 0;
+    for (int i = 0; i < nseg; ++i) sum += seg_c[i];
+    if (sum != Cin || (k != 3 && k != 1)) return RSU_EINVAL;
+    // HWIO: element (tap, ci, co) at (tap*Cin + ci)*Cout + co; rows = co, k = ci
+    return do_pack(w, packed, k * k, Cout, seg_c, nseg, (long)Cin * Cout, 1, Cout, 0, (hipStream_t)stream);
+}
+extern "C" int rsu_pack_conv_bwd(const float* w, void* packed, int k, int Cin_total, int ci_off, int ci_cnt, int Cout,
+                                 rsu_stream_t stream) {
+    int seg[1] = {Cout};
+    if (!w || ci_off < 0 || ci_cnt < 1 || ci_off + ci_cnt > Cin_total) return RSU_EINVAL;
+    // rows = ci (of the slice), k = co, taps flipped
+    return do_pack(w + (long)ci_off * Cout, packed, k * k, ci_cnt, seg, 1, (long)Cin_total * Cout, Cout, 1, 1, (hipStream_t)stream);
+}
+extern "C" int rsu_pack_convT_fwd(const float* K, void* packed, int Cin, int Cout, rsu_stream_t stream) {
+    int seg[1] = {Cin};
+    // K [a][b][co][ci]: four single-tap matrices, laid out back to back (one per output phase)
+    const size_t per = rsu_packed_bytes(1, Cout, seg, 1);
+    for (int ab = 0; ab < 4; ++ab) {
+        int rc = do_pack(K + (long)ab * Cout * Cin, (char*)packed + ab * per, 1, Cout, seg, 1, 0, Cin, 1, 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return RSU_OK;
+}
+extern "C" int rsu_pack_convT_bwd(const float* K, void* packed, int Cin, int Cout, rsu_stream_t stream) {
+    int seg[1] = {Cout};
+    // rows = ci, k = co, 4 taps (a,b) unflipped
+    return do_pack(K, packed, 4, Cin, seg, 1, (long)Cout * Cin, 1, Cin, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// VALU head / tail
+// ---------------------------------------------------------------------------------------------
+extern "C" int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix, rsu_stream_t stream) {
+    if (!x || !w || !b || !out16 || npix < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_color_adjust(x, w, b, out16, npix, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil,
+                                  rsu_stream_t stream) {
+    if (!in16 || !w || !y || Cout % 8 || Cout > 512 || H <= 2 * dil || W <= 2 * dil || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_conv_first_fwd(in16, w, b, y, N, H, W, Cout, dil, (hipStream_t)stream));
+    return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// igemm_fwd family
+// ---------------------------------------------------------------------------------------------
+struct FwdPlan { int cfg; TileGeo g; int ncob; };
+static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int force_cfg) {
+    static const int order64[] = {IGF_CFG_64x256, IGF_CFG_64x128};
+    static const int order128[] = {IGF_CFG_128x256, IGF_CFG_128x128, IGF_CFG_128x64};
+    const bool narrow = Cout <= 64;
+    const int* order = narrow ? order64 : order128;
+    const int norder = narrow ? 2 : 3;
+    bool have = false;
+    for (int i = 0; i < norder; ++i) {
+        const int cfg = force_cfg >= 0 ? force_cfg : order[i];
+        const IgFwdCfgInfo ci = igemm_fwd_cfg_info(cfg);
+        if (ci.TN == 0) return false;
+        const size_t wbytes = igemm_fwd_lds_bytes(cfg, ntap, 0);
+        const int cap = (int)((160 * 1024 - (long)wbytes) / 128);
+        TileGeo g;
+        if (!plan_geo(g, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) {
+            if (force_cfg >= 0) return false;
+            continue;
+        }
+        pl.cfg = cfg;
+        pl.g = g;
+        pl.ncob = cdiv(Cout, ci.TN);
+        have = true;
+        const long wgs = (long)N * g.nstrips * g.tiles_per_strip * pl.ncob;
+        if (force_cfg >= 0 || wgs >= 384) break;  // enough workgroups to fill 256 CUs; else try a smaller tile
+    }
+    return have;
+}
+
+static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
+                   void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
+    const int kh = ntap / kw;
+    FwdPlan pl;
+    if (!plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
+    IgFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.nsrc = nsrc;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].ptr || srcs[i].C % 8) return RSU_EINVAL;
+        if (srcs[i].oy < 0 || srcs[i].ox < 0 || srcs[i].oy + Hin > srcs[i].H || srcs[i].ox + Win > srcs[i].W) return RSU_EINVAL;
+        p.src[i].ptr = (const bf16_t*)srcs[i].ptr;
+        p.src[i].H = srcs[i].H;
+        p.src[i].W = srcs[i].W;
+        p.src[i].C = srcs[i].C;
+        p.src[i].oy = srcs[i].oy;
+        p.src[i].ox = srcs[i].ox;
+        p.nchunk[i] = cdiv(srcs[i].C, 32);
+    }
+    p.wp = (const bf16_t*)wp;
+    p.wp_y_stride = wp_y_stride;
+    p.ntiles_w = ntiles_w;
+    p.tile_off = tile_off;
+    p.bias = bias;
+    p.out = (bf16_t*)out;
+    p.mask_src = (const bf16_t*)mask_src;
+    p.zero_page = zero_page();
+    if (!p.zero_page) return RSU_EHIP;
+    p.N = N; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
+    p.Cout = Cout; p.outC = outC;
+    p.dil = dil; p.stride = stride; p.pad = pad;
+    p.oH = oH; p.oW = oW; p.ostride = ostride;
+    p.relu = relu; p.accumulate = accumulate;
+    p.ncob = pl.ncob;
+    p.g = pl.g;
+    const long gx = (long)N * pl.g.nstrips * pl.g.tiles_per_strip * pl.ncob;
+    if (gx > 0x7fffffffL) return RSU_EINVAL;
+    HIP_CHECK_RET(igemm_fwd_launch(pl.cfg, ntap, p, (int)gx, gy, st));
+    return RSU_OK;
+}
+
+extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
+                              int Win, int Cout, int dil, int relu, rsu_stream_t stream) {
+    if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || Cout % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    const int Ho = Hin - 2 * dil, Wo = Win - 2 * dil;
+    if (Ho < 1 || Wo < 2) return RSU_EINVAL;
+    return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
+                   Ho, Wo, 1, 1, relu, 0, (hipStream_t)stream);
+}
+
+extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
+                                   int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, rsu_stream_t stream) {
+    if (!dz || !packed_bwd || !dx || Cout % 8 || ci_cnt % 8 || ci_off % 32 || ci_off + ci_cnt > Cin_total || (dil != 1 && dil != 2))
+        return RSU_EINVAL;
+    const int Hd = H - 2 * dil, Wd = W - 2 * dil;  // dz size
+    if (Hd < 1 || Wd < 1 || W < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = dz; s.H = Hd; s.W = Wd; s.C = Cout; s.oy = 0; s.ox = 0;
+    return run_fwd(&s, 1, packed_bwd, 0, rup(Cin_total, 128) / 16, ci_off / 16, nullptr, dx, relu_src, N, Hd, Wd, H, W, ci_cnt, ci_cnt, 9,
+                   3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                                rsu_stream_t stream) {
+    if (!x || !packed_fwd || !y || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = x; s.H = H; s.W = W; s.C = Cin; s.oy = 0; s.ox = 0;
+    int seg[1] = {Cin};
+    const long per = (long)(rsu_packed_bytes(1, Cout, seg, 1) / 2);
+    return run_fwd(&s, 1, packed_fwd, per, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, H, W, H, W, Cout, Cout, 1, 1, 1, 1, 0, 2 * H, 2 * W,
+                   2, 4, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, int N, int H, int W, int Cin,
+                                     int Cout, rsu_stream_t stream) {
+    if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
+    return run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0, H, W,
+                   1, 1, 0, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// igemm_wgrad family
+// ---------------------------------------------------------------------------------------------
+static int wgrad_max_split(int Cf, int Cs, int csb) {
+    int want = 512 / (cdiv(Cf, 64) * cdiv(Cs, csb));
+    return want < 1 ? 1 : want;
+}
+struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles; };
+static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
+    pl.cfg = cfg;
+    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
+    const int tmk = igemm_wgrad_tmk(cfg);
+    const long fixed = 2L * tmk * 128;
+    const int cap = (int)((160 * 1024 - fixed) / (2 * csb * 2));
+    if (!plan_geo(pl.g, Hf, Wf, tmk, kh, kw, dil, stride, cap)) return false;
+    pl.gx = cdiv(Cf, 64);
+    pl.gy = cdiv(Cs, csb);
+    pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
+    const int want = wgrad_max_split(Cf, Cs, csb);
+    pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
+    (void)ntap;
+    return true;
+}
+
+static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st) {
+    WgPlan pl;
+    if (!plan_wgrad(pl, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
+    IgWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.F = (const bf16_t*)F;
+    p.Hf = Hf; p.Wf = Wf; p.Cf = Cf;
+    p.S.ptr = (const bf16_t*)S->ptr;
+    p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
+    p.slab = ws;
+    p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
+    p.zero_page = zero_page();
+    if (!p.zero_page) return RSU_EHIP;
+    p.N = N; p.dil = dil; p.stride = stride;
+    p.nsplit = pl.nsplit;
+    p.ntiles_total = pl.ntiles;
+    p.g = pl.g;
+    HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
+    HIP_CHECK_RET(ew_reduce_slabs(ws, out, pl.nsplit, ntap, CsOut, cs_off, S->C, CfOut, st));
+    return RSU_OK;
+}
+
+extern "C" size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout) {
+    return (size_t)wgrad_max_split(Cout, src_C, 64) * 9 * Cin_total * Cout;
+}
+extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* ws, int N, int Ho, int Wo, int Cin_total,
+                                     int ci_off, int Cout, int dil, rsu_stream_t stream) {
+    if (!src || !src->ptr || !dz || !dw || !ws || src->C % 8 || Cout % 8 || ci_off + src->C > Cin_total || (dil != 1 && dil != 2))
+        return RSU_EINVAL;
+    if (src->oy < 0 || src->ox < 0 || src->oy + Ho + 2 * dil > src->H || src->ox + Wo + 2 * dil > src->W || Wo < 2) return RSU_EINVAL;
+    // F = dz (cf = co), S = layer input (cs = ci): slab[tap][ci][co] = HWIO
+    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, (hipStream_t)stream);
+}
+
+extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
+    return (size_t)wgrad_max_split(Cin, Cout, 64) * 4 * Cout * Cin;
+}
+extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin, int Cout,
+                                       rsu_stream_t stream) {
+    if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
+    // F = x (cf = ci), S = dy (cs = co), stride 2: slab[tap(a,b)][co][ci] = K layout
+    return run_wgrad(IGW_CFG_64x64, x, H, W, Cin, &s, dK, ws, Cout, Cin, 0, N, 4, 2, 1, 2, (hipStream_t)stream);
+}
+
+extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {
+    return (size_t)(wgrad_max_split(Cout, 16, 16) + 1) * 9 * 16 * Cout;
+}
+extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* ws, int N, int H, int W, int Cout,
+                                         int dil, rsu_stream_t stream) {
+    if (!in16 || !dz || !dw1 || !ws || Cout % 8 || (dil != 1 && dil != 2) || W - 2 * dil < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
+    float* tmp = ws;                          // [9][16][Cout]
+    float* slabs = ws + (size_t)9 * 16 * Cout;
+    int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));
+    return RSU_OK;
+}
+
+extern "C" size_t rsu_bias_grad_ws_floats(long npix, int C) { return (size_t)ew_colsum_blocks(npix, C) * C; }
+extern "C" int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_stream_t stream) {
+    if (!dz || !db || !ws || C < 8 || C % 8 || C > 2048 || 256 % (C / 8) || npix < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_colsum(dz, db, ws, npix, C, (hipStream_t)stream));
+    return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pool, head, optimizer, tiler
+// ---------------------------------------------------------------------------------------------
+extern "C" int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, rsu_stream_t stream) {
+    if (!x || !y || C % 8 || H < 2 || W < 2) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_maxpool_fwd(x, y, N, H, W, C, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C,
+                                      int Hs, int Ws, rsu_stream_t stream) {
+    if (!y_act || !dz || C % 8) return RSU_EINVAL;
+    if (dskip && (Hs > H || Ws > W || Hs < 1 || Ws < 1)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_pool_skip_relu_bwd(y_act, dpool, dskip, dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, (hipStream_t)stream));
+    return RSU_OK;
+}
+static bool head_c_ok(int C) { return C >= 8 && C <= 512 && (C % 8) == 0 && ((C / 8) & (C / 8 - 1)) == 0; }
+extern "C" int rsu_head_fwd(const void* act, const float* w, const float* b, float* prob, float* logits, long npix, int C,
+                            rsu_stream_t stream) {
+    if (!act || !w || !b || !prob || !head_c_ok(C) || npix < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_head(false, act, w, b, nullptr, prob, logits, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, 0.f, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" size_t rsu_head_ws_floats(long npix, int C) { return (size_t)ew_head_blocks(npix, C) * (2 * C + 3); }
+extern "C" int rsu_head_fwd_bwd(const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* loss_sum,
+                                void* dact, float* dw, float* db, float* ws, long npix, int C, float inv_count, rsu_stream_t stream) {
+    if (!act || !w || !b || !labels || !prob || !loss_sum || !dact || !dw || !db || !ws || !head_c_ok(C) || npix < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_head(true, act, w, b, labels, prob, nullptr, dact, dw, db, loss_sum, ws, npix, C, inv_count, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_momentum_step(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, rsu_stream_t stream) {
+    if (!w || !acc || !g || n < 1) return RSU_EINVAL;
+    if (((uintptr_t)w | (uintptr_t)acc | (uintptr_t)g) & 15) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_momentum(w, acc, g, lr, mu, gscale, n, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_extract_tiles(const float* imgs, float* tiles, int nimg, int H, int S, int P, int stride, long t0, long ntiles,
+                                 rsu_stream_t stream) {
+    // images.py:60-61 asserts + tf_aerial_images.py:288-293 geometry
+    if (!imgs || !tiles || P > S || (S - P) % 2 || P > H || stride < 1 || (H - P) % stride || (S - P) / 2 > H) return RSU_EINVAL;
+    const int pps = (H - P) / stride + 1;
+    if (t0 < 0 || ntiles < 1 || t0 + ntiles > (long)nimg * pps * pps) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_extract_tiles(imgs, tiles, H, S, P, stride, pps, t0, ntiles, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, long t0, long ntiles,
+                               rsu_stream_t stream) {
+    if (!prob || !acc || !hits || P > H || stride < 1 || (H - P) % stride) return RSU_EINVAL;
+    const int pps = (H - P) / stride + 1;
+    if (t0 < 0 || ntiles < 1 || t0 + ntiles > (long)nimg * pps * pps) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_overlap_add(prob, acc, hits, nimg, H, P, stride, pps, t0, ntiles, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_overlap_finish(const float* acc, const float* hits, float* out, long n, rsu_stream_t stream) {
+    if (!acc || !hits || !out || n < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_overlap_finish(acc, hits, out, n, (hipStream_t)stream));
+    return RSU_OK;
+}

@@ -1,0 +1,62 @@
+// Shared device/host helpers for the gfx950 kernels of librsu_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // one MFMA A/B fragment (8 bf16, 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;  // one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(4))) float f32x4;   // one 16x16 accumulator tile slice
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define RSU_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// round-to-nearest-even (plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    f2 v = {lo, hi};
+    b2 r = __builtin_convertvector(v, b2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 r = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, r);
+}
+
+// ---- async global -> LDS copy, 16 bytes per lane (LDS destination = wave-uniform base + lane*16)
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---- exact division of a non-negative int by a runtime constant d >= 2: q = umulhi(n, ceil(2^32/d)),
+// exact while n * d < 2^32 (host side: magic32() in rsu_api.hip)
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
+
+// Tile geometry shared by the implicit-GEMM kernels. Output pixels of one image are cut into vertical
+// strips of width SW; inside a strip pixels are flattened row-major (m = y*SW + tx) and a workgroup
+// takes TM consecutive m. The input rows/cols such a tile touches are staged in LDS as a dense
+// [R][CW] pixel image ("halo tile").
+struct TileGeo {
+    int SW;               // strip width (output pixels)
+    int nstrips;          // ceil(Wo / SW)
+    int tiles_per_strip;  // ceil(Ho*SW / TM)
+    int CW;               // halo tile row pitch in pixels: (SW-1)*stride + (KW-1)*dil + 1, rounded up to 8
+    int npix_max;         // LDS pixels reserved per buffer (multiple of 16)
+    unsigned inv_SW, inv_CW;  // div_magic constants
+};
+
+#define HIP_CHECK_RET(x)                     \
+    do {                                     \
+        hipError_t e__ = (x);                \
+        if (e__ != hipSuccess) {             \
+            rsu_set_hip_error((int)e__);     \
+            return RSU_EHIP;                 \
+        }                                    \
+    } while (0)

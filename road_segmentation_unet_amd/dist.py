@@ -1,0 +1,72 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-device (tf_aerial_images.py:387-393); data parallelism is new here. The global minibatch is
+sharded over ranks (same shuffle on every rank, rank r takes its slice), weights and Momentum slots are replicated,
+and the per-rank gradients -- already scaled by 1/(GLOBAL pixel count) in the head kernel -- are SUM-all-reduced,
+which equals the reference's reduce_mean over the whole batch (tf_aerial_images.py:108).
+
+Gradients live in one flat float32 buffer in variable-creation order; backward produces them from the END of the
+buffer towards the START (head, decoder stages, encoder levels, colour adjust), so each finished block is a
+contiguous tail slice: it is all-reduced on a side stream while the remaining backward kernels run.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are whole blocks (MBs, not KBs) so each ring step
+moves large messages; the dead conv_dilut_{L-1} variables sit after `n_live` and are never sent.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(indices, offset, global_batch, rank, world_size):
+    """Indices of the patches rank `rank` processes for the step starting at `offset` of the shuffled index list
+    (tf_aerial_images.py:232-233 batch slicing, split contiguously over ranks)."""
+    assert global_batch % world_size == 0, "global batch must divide evenly over ranks"
+    per = global_batch // world_size
+    lo = offset + rank * per
+    return indices[lo:lo + per]
+
+
+class GradBucketer:
+    """All-reduce a flat gradient buffer in tail-first buckets, overlapped with the producer.
+
+    flat: 1-D float32 tensor (CPU with gloo, GPU with nccl); n_live: prefix length that takes part.
+    Call ready(lo) when every gradient at positions >= lo has been produced (monotonically decreasing lo), then
+    finish() before the optimizer step."""
+
+    def __init__(self, flat, n_live, group=None, min_bucket_elems=1 << 20):
+        self.flat, self.n_live, self.group = flat, n_live, group
+        self.min_bucket = min_bucket_elems
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.reset()
+
+    def reset(self):
+        self.hi = self.n_live
+        self.pending = []
+
+    def _launch(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, lo):
+        lo = max(0, min(lo, self.hi))
+        if self.hi - lo >= self.min_bucket:
+            self._launch(lo, self.hi)
+            self.hi = lo
+
+    def finish(self):
+        self._launch(0, self.hi)
+        self.hi = 0
+        for w in self.pending:
+            w.wait()
+        if self.cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+        self.pending = []

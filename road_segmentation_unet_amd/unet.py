@@ -1,0 +1,474 @@
+"""Host-side mirror of the reference's network definition (/root/reference/src/unet.py) over the HIP C ABI.
+
+`input_size_needed` and `forward` keep the reference's names, argument meaning and error behaviour
+(unet.py:12, unet.py:100); `UNet` owns what the TF graph + session owned: the variables (TF names, TF
+layouts, float32), their Momentum slots, the activation buffers and the backward pass
+(tf_aerial_images.py:103-122). PyTorch is only the device-memory / stream / collective plumbing: every
+arithmetic kernel on the path is a hand-written HIP kernel reached through librsu_hip.so.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import RsuSrc, call
+
+NUM_CHANNELS = 3  # src/constants.py:3
+NUM_LABELS = 2    # src/constants.py:4
+
+
+def input_size_needed(output_size, num_layers):
+    """Utility function to compute image size for a given U-Net output (reference: unet.py:100-115).
+
+    Same arithmetic, same AssertionError text as the reference."""
+    for i in range(num_layers - 1):
+        assert output_size % 2 == 0, 'expand layer {} has size {} not divisible by 2' \
+            .format(num_layers - i, output_size)
+        output_size = (output_size + 4) / 2
+    for i in range(num_layers - 1):
+        output_size = (output_size + 4) * 2
+    return int(output_size + 4)
+
+
+def param_shapes(num_layers, root_size, dilated_layers):
+    """(name, shape) of every variable unet.forward creates, in creation order (unet.py:23,34-45,67,88-91,95)."""
+    shapes = [("color_space_adjust/kernel", (1, 1, 3, 3)), ("color_space_adjust/bias", (3,))]
+    nf, cin = root_size, NUM_CHANNELS
+    for i in range(num_layers):
+        if dilated_layers:
+            shapes += [("conv_dilut_%d/atrous_conv1/kernel" % i, (3, 3, cin, nf)), ("conv_dilut_%d/atrous_conv1/bias" % i, (nf,)),
+                       ("conv_dilut_%d/atrous_conv2/kernel" % i, (3, 3, nf, nf)), ("conv_dilut_%d/atrous_conv2/bias" % i, (nf,))]
+        shapes += [("conv_%d/conv1/kernel" % i, (3, 3, cin, nf)), ("conv_%d/conv1/bias" % i, (nf,)),
+                   ("conv_%d/conv2/kernel" % i, (3, 3, nf, nf)), ("conv_%d/conv2/bias" % i, (nf,))]
+        cin = nf
+        nf *= 2
+    nf //= 2
+    for i in range(num_layers - 1):
+        nf //= 2
+        shapes += [("up_conv_%d/kernel" % i, (2, 2, nf, 2 * nf)), ("up_conv_%d/bias" % i, (nf,))]
+        ccat = (3 if dilated_layers else 2) * nf
+        j = num_layers + i
+        shapes += [("conv_%d/conv1/kernel" % j, (3, 3, ccat, nf)), ("conv_%d/conv1/bias" % j, (nf,)),
+                   ("conv_%d/conv2/kernel" % j, (3, 3, nf, nf)), ("conv_%d/conv2/bias" % j, (nf,))]
+    shapes += [("weight_output/kernel", (1, 1, nf, NUM_LABELS)), ("weight_output/bias", (NUM_LABELS,))]
+    return shapes
+
+
+def _is_dead(name, num_layers):
+    """The level L-1 dilated pair is built but never consumed (unet.py:57-59): no gradient, never updated."""
+    return name.startswith("conv_dilut_%d/" % (num_layers - 1))
+
+
+def glorot_uniform_params(num_layers, root_size, dilated_layers, seed):
+    """tf.layers defaults: glorot_uniform kernels, zero biases. (TF's own seeds are op-id derived and not
+    reproducible outside TF; parity tests inject identical weights instead.)"""
+    rng = np.random.RandomState(seed)
+    out = {}
+    for name, shp in param_shapes(num_layers, root_size, dilated_layers):
+        if name.endswith("kernel"):
+            recept = shp[0] * shp[1]
+            limit = math.sqrt(6.0 / (recept * shp[2] + recept * shp[3]))
+            out[name] = rng.uniform(-limit, limit, size=shp).astype(np.float32)
+        else:
+            out[name] = np.zeros(shp, np.float32)
+    return out
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _src(t, h, w):
+    """window (h, w) centred in NHWC tensor t (crop offset floor((H-h)/2), unet.py:70-83)"""
+    H, W, C = t.shape[1], t.shape[2], t.shape[3]
+    return RsuSrc(t.data_ptr(), H, W, C, (H - h) // 2, (W - w) // 2)
+
+
+class UNet:
+    """Variables + buffers + forward/backward of the U-Net for a FIXED (batch, patch_size) -- the reference's graph is
+    static in exactly the same way (tf_aerial_images.py:133-138)."""
+
+    def __init__(self, num_layers, root_size, dilated_layers, batch_size, patch_size, device="cuda:0", params=None, seed=2017,
+                 training=True):
+        assert root_size % 8 == 0 and (root_size // 8) & (root_size // 8 - 1) == 0, "root_size must be 8 * 2^k for the HIP path"
+        self.L, self.root, self.dilated = num_layers, root_size, bool(dilated_layers)
+        self.B, self.P = batch_size, patch_size
+        self.S = input_size_needed(patch_size, num_layers)
+        self.device = torch.device(device)
+        self.training = training
+        self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
+        self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
+        _lib.lib()  # fail loudly now if the HIP extension is missing
+        self._alloc_params(params if params is not None else glorot_uniform_params(num_layers, root_size, dilated_layers, seed))
+        self._alloc_buffers()
+        self.repack()
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self, init):
+        shapes = param_shapes(self.L, self.root, self.dilated)
+        live = [(n, s) for n, s in shapes if not _is_dead(n, self.L)]
+        dead = [(n, s) for n, s in shapes if _is_dead(n, self.L)]
+        self.names = [n for n, _ in shapes]
+        off, self._slices = 0, {}
+        for n, s in live + dead:
+            if n == (dead[0][0] if dead else None):
+                self.n_live = off
+            cnt = int(np.prod(s))
+            self._slices[n] = (off, cnt, s)
+            off += (cnt + 3) // 4 * 4  # 16-byte aligned starts
+        if not dead:
+            self.n_live = off
+        self.n_flat = off
+        dev = self.device
+        self.flat_w = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_acc = torch.zeros(off, dtype=torch.float32, device=dev)   # Momentum slots (tf_aerial_images.py:120)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.w, self.acc, self.g = {}, {}, {}
+        for n, (o, cnt, s) in self._slices.items():
+            self.w[n] = self.flat_w[o:o + cnt].view(s)
+            self.acc[n] = self.flat_acc[o:o + cnt].view(s)
+            self.g[n] = self.flat_g[o:o + cnt].view(s)
+            self.w[n].copy_(torch.from_numpy(np.ascontiguousarray(init[n], dtype=np.float32)))
+        self.global_step = 0
+
+    def state_dict(self):
+        """TF variable names, TF layouts (HWIO / [kh,kw,out,in]) + Momentum slots + global_step."""
+        d = {n: self.w[n].detach().cpu().numpy().copy() for n in self.names}
+        d.update({n + "/Momentum": self.acc[n].detach().cpu().numpy().copy() for n in self.names})
+        d["global_step"] = np.int64(self.global_step)
+        return d
+
+    def load_state_dict(self, d):
+        for n in self.names:
+            self.w[n].copy_(torch.from_numpy(np.ascontiguousarray(d[n], dtype=np.float32)))
+            if n + "/Momentum" in d:
+                self.acc[n].copy_(torch.from_numpy(np.ascontiguousarray(d[n + "/Momentum"], dtype=np.float32)))
+        self.global_step = int(d.get("global_step", 0))
+        self.repack()
+
+    # ------------------------------------------------------------------ buffers
+    def _bf(self, *shape):
+        return torch.zeros(shape, dtype=torch.bfloat16, device=self.device)
+
+    def _alloc_buffers(self):
+        B, L, S = self.B, self.L, self.S
+        dev = self.device
+        self.x = torch.zeros((B, S, S, 3), dtype=torch.float32, device=dev)
+        self.in16 = self._bf(B, S, S, 16)
+        self.act, self.grad = {}, {}
+        h, nf = S, self.root
+        self.level_in = {}
+        for i in range(L):
+            self.level_in[i] = h
+            if self.dilated and i < L - 1:
+                self.act["d1_%d" % i] = self._bf(B, h - 4, h - 4, nf)
+                self.act["d2_%d" % i] = self._bf(B, h - 8, h - 8, nf)
+            self.act["c1_%d" % i] = self._bf(B, h - 2, h - 2, nf)
+            self.act["c2_%d" % i] = self._bf(B, h - 4, h - 4, nf)
+            if i < L - 1:
+                assert (h - 4) % 2 == 0
+                self.act["pool_%d" % i] = self._bf(B, (h - 4) // 2, (h - 4) // 2, nf)
+                h = (h - 4) // 2
+                nf *= 2
+        h = h - 4
+        for i in range(L - 1):
+            nf //= 2
+            j = L + i
+            self.act["up_%d" % i] = self._bf(B, 2 * h, 2 * h, nf)
+            h = 2 * h
+            self.act["c1_%d" % j] = self._bf(B, h - 2, h - 2, nf)
+            self.act["c2_%d" % j] = self._bf(B, h - 4, h - 4, nf)
+            h -= 4
+        assert h == self.P, (h, self.P)
+        self.last_name = "c2_%d" % (2 * L - 2) if L > 1 else "c2_0"
+        self.prob = torch.zeros((B, self.P, self.P), dtype=torch.float32, device=dev)
+        self.logits = torch.zeros((B, self.P, self.P, 2), dtype=torch.float32, device=dev)
+        self.labels = torch.zeros((B, self.P, self.P), dtype=torch.int64, device=dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.training:
+            for k, t in self.act.items():
+                if k.startswith("up_") or k.startswith("c") or k.startswith("d") or k.startswith("pool_"):
+                    self.grad[k] = torch.zeros_like(t)
+            # cropped skip gradients (decoder conv1 bwd-data outputs for the skip sources)
+            for i in range(L - 1):
+                up = self.act["up_%d" % i]
+                self.grad["skip_%d" % i] = torch.zeros_like(up)
+                if self.dilated:
+                    self.grad["skipd_%d" % i] = torch.zeros_like(up)
+            lib = _lib.lib()
+            ws = [lib.rsu_head_ws_floats(B * self.P * self.P, self.root), lib.rsu_conv_first_bwd_ws_floats(self.root)]
+            for n, (_, _, s) in self._slices.items():
+                if n.endswith("kernel") and len(s) == 4 and s[0] == 3 and s[2] != 3:
+                    srcs = self._conv_sources_c(n, s)
+                    for c in srcs:
+                        ws.append(lib.rsu_conv2d_bwd_weight_ws_floats(s[2], c, s[3]))
+                    ws.append(lib.rsu_bias_grad_ws_floats(B * S * S, s[3]))
+                if n.startswith("up_conv") and n.endswith("kernel"):
+                    ws.append(lib.rsu_convT2x2_bwd_weight_ws_floats(s[3], s[2]))
+            self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
+            self.gfirst = torch.zeros((2, 3, 3, 3, self.root), dtype=torch.float32, device=dev)  # gxc of conv1 / atrous_conv1
+
+    def _conv_sources_c(self, name, shape):
+        """channel counts of the concat sources feeding conv `name` (decoder conv1: [skip,(dil skip),up], unet.py:79/85)"""
+        cin, cout = shape[2], shape[3]
+        blk = int(name.split("/")[0].split("_")[-1]) if name.startswith("conv_") and not name.startswith("conv_dilut") else -1
+        if name.endswith("conv1/kernel") and blk >= self.L:
+            return [cout] * (3 if self.dilated else 2)
+        return [cin]
+
+    # ------------------------------------------------------------------ packed bf16 weights
+    def repack(self):
+        """float32 master weights -> bf16 MFMA fragment order (after init / load / every optimizer step)."""
+        lib = _lib.lib()
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
+        first = not hasattr(self, "pk")
+        if first:
+            self.pk = {}
+        for n, (_, _, s) in self._slices.items():
+            if not n.endswith("kernel") or _is_dead(n, self.L):
+                continue
+            if n.startswith("up_conv"):
+                cout, cin = s[2], s[3]
+                if first:
+                    seg = (ctypes.c_int * 1)(cin)
+                    self.pk[n, "fwd"] = torch.zeros(4 * lib.rsu_packed_bytes(1, cout, seg, 1) // 2, dtype=torch.bfloat16, device=self.device)
+                    seg = (ctypes.c_int * 1)(cout)
+                    self.pk[n, "bwd"] = torch.zeros(lib.rsu_packed_bytes(4, cin, seg, 1) // 2, dtype=torch.bfloat16, device=self.device)
+                call("rsu_pack_convT_fwd", _ptr(self.w[n]), _ptr(self.pk[n, "fwd"]), cin, cout, st)
+                if self.training:
+                    call("rsu_pack_convT_bwd", _ptr(self.w[n]), _ptr(self.pk[n, "bwd"]), cin, cout, st)
+            elif s[0] == 3 and s[2] != NUM_CHANNELS:
+                cin, cout = s[2], s[3]
+                segs = self._conv_sources_c(n, s)
+                seg = (ctypes.c_int * len(segs))(*segs)
+                if first:
+                    self.pk[n, "fwd"] = torch.zeros(lib.rsu_packed_bytes(9, cout, seg, len(segs)) // 2, dtype=torch.bfloat16, device=self.device)
+                    seg1 = (ctypes.c_int * 1)(cout)
+                    for si, c in enumerate(segs):  # one backward-data pack per concat source
+                        self.pk[n, "bwd", si] = torch.zeros(lib.rsu_packed_bytes(9, c, seg1, 1) // 2, dtype=torch.bfloat16, device=self.device)
+                call("rsu_pack_conv_fwd", _ptr(self.w[n]), _ptr(self.pk[n, "fwd"]), 3, cin, cout, seg, len(segs), st)
+                if self.training:
+                    off = 0
+                    for si, c in enumerate(segs):
+                        call("rsu_pack_conv_bwd", _ptr(self.w[n]), _ptr(self.pk[n, "bwd", si]), 3, cin, off, c, cout, st)
+                        off += c
+
+    # ------------------------------------------------------------------ forward
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _timed(self, tag, flops, fn, *args):
+        """call an ABI entry point; when profiling, bracket it with events on the launch stream"""
+        if self.prof is None:
+            call(fn, *args)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call(fn, *args)
+        e1.record()
+        self.prof.append((tag, flops, e0, e1))
+
+    def _grads_ready(self, name):
+        if self.on_grads is not None:
+            self.on_grads(self._slices[name][0])
+
+    def _conv(self, name, srcs, hin, out, dil=1):
+        arr = (RsuSrc * len(srcs))(*srcs)
+        cout = out.shape[3]
+        cin = sum(s.C for s in srcs)
+        ho = hin - 2 * dil
+        self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd", arr, len(srcs),
+                    _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
+                    self._stream())
+
+    def forward_device(self, want_logits=False):
+        """unet.forward (unet.py:12-97) on self.x (already on device) with dropout_keep = 1.0; fills self.prob."""
+        B, L, S, st, a = self.B, self.L, self.S, self._stream(), self.act
+        call("rsu_color_adjust_fwd", _ptr(self.x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
+             _ptr(self.in16), B * S * S, st)
+        cur, h = None, S
+        for i in range(L):
+            last = i == L - 1
+            if self.dilated and not last:
+                if i == 0:
+                    call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.w["conv_dilut_0/atrous_conv1/kernel"]),
+                         _ptr(self.w["conv_dilut_0/atrous_conv1/bias"]), _ptr(a["d1_0"]), B, h, h, self.root, 2, st)
+                else:
+                    self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
+                self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
+            if i == 0:
+                call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.w["conv_0/conv1/kernel"]), _ptr(self.w["conv_0/conv1/bias"]),
+                     _ptr(a["c1_0"]), B, h, h, self.root, 1, st)
+            else:
+                self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i])
+            self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
+            if not last:
+                c2 = a["c2_%d" % i]
+                call("rsu_maxpool2x2_fwd", _ptr(c2), _ptr(a["pool_%d" % i]), B, h - 4, h - 4, c2.shape[3], st)
+                cur, h = a["pool_%d" % i], (h - 4) // 2
+        net, h = a["c2_%d" % (L - 1)], h - 4
+        for i in range(L - 1):
+            j, lvl = L + i, L - 2 - i
+            up = a["up_%d" % i]
+            call("rsu_convT2x2_fwd", _ptr(net), _ptr(self.pk["up_conv_%d/kernel" % i, "fwd"]), _ptr(self.w["up_conv_%d/bias" % i]), _ptr(up),
+                 B, h, h, net.shape[3], up.shape[3], st)
+            h = 2 * h
+            srcs = [_src(a["c2_%d" % lvl], h, h)]
+            if self.dilated:
+                srcs.append(_src(a["d2_%d" % lvl], h, h))
+            srcs.append(_src(up, h, h))
+            self._conv("conv_%d/conv1" % j, srcs, h, a["c1_%d" % j])
+            self._conv("conv_%d/conv2" % j, [_src(a["c1_%d" % j], h - 2, h - 2)], h - 2, a["c2_%d" % j])
+            net, h = a["c2_%d" % j], h - 4
+        if not self.training or want_logits:
+            call("rsu_head_fwd", _ptr(net), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.prob),
+                 _ptr(self.logits) if want_logits else None, B * self.P * self.P, self.root, st)
+        return net
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, name, srcs_t, dz, hout, dil=1):
+        """dW (HWIO rows per source) + db of conv `name`; srcs_t = list of (tensor, window size)"""
+        st = self._stream()
+        cout = dz.shape[3]
+        cin_total = self.w[name + "/kernel"].shape[2]
+        off = 0
+        for t, win in srcs_t:
+            s = _src(t, win, win)
+            self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
+                        _ptr(dz), _ptr(self.g[name + "/kernel"]), _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
+            off += t.shape[3]
+        call("rsu_bias_grad", _ptr(dz), _ptr(self.g[name + "/bias"]), _ptr(self.ws), self.B * hout * hout, cout, st)
+
+    def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
+        """Conv2DBackpropInput towards concat source `src_index` of conv `name` (its own weight pack)"""
+        cout = self.w[name + "/kernel"].shape[3]
+        cnt = dx.shape[3]
+        ho = hin - 2 * dil
+        self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data", _ptr(dz),
+                    _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
+                    cout, dil, self._stream())
+
+    def backward_device(self, inv_count):
+        """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count)."""
+        B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
+        last = a[self.last_name]
+        self.loss_sum.zero_()
+        call("rsu_head_fwd_bwd", _ptr(last), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.labels),
+             _ptr(self.prob), _ptr(self.loss_sum), _ptr(g[self.last_name]), _ptr(self.g["weight_output/kernel"]),
+             _ptr(self.g["weight_output/bias"]), _ptr(self.ws), B * self.P * self.P, self.root, inv_count, st)
+        # ---- decoder, stage L-2 .. 0
+        for i in reversed(range(L - 1)):
+            j, lvl = L + i, L - 2 - i
+            c1, c2, up = a["c1_%d" % j], a["c2_%d" % j], a["up_%d" % i]
+            h = up.shape[1]
+            nf = c2.shape[3]
+            dz2, dz1 = g["c2_%d" % j], g["c1_%d" % j]
+            self._wgrad("conv_%d/conv2" % j, [(c1, h - 2)], dz2, h - 4)
+            self._bwd_data("conv_%d/conv2" % j, dz2, dz1, h - 2, relu_src=c1)
+            srcs = [(a["c2_%d" % lvl], h)] + ([(a["d2_%d" % lvl], h)] if self.dilated else []) + [(up, h)]
+            self._wgrad("conv_%d/conv1" % j, srcs, dz1, h - 2)
+            self._bwd_data("conv_%d/conv1" % j, dz1, g["skip_%d" % i], h, src_index=0)
+            if self.dilated:
+                self._bwd_data("conv_%d/conv1" % j, dz1, g["skipd_%d" % i], h, src_index=1)
+            dup = g["up_%d" % i]
+            self._bwd_data("conv_%d/conv1" % j, dz1, dup, h, src_index=2 if self.dilated else 1)
+            # transposed conv
+            upin = a["c2_%d" % (j - 1)] if i > 0 else a["c2_%d" % (L - 1)]
+            gin = g["c2_%d" % (j - 1)] if i > 0 else g["c2_%d" % (L - 1)]
+            hh = h // 2
+            call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.ws), B, hh, hh,
+                 upin.shape[3], nf, st)
+            call("rsu_bias_grad", _ptr(dup), _ptr(self.g["up_conv_%d/bias" % i]), _ptr(self.ws), B * h * h, nf, st)
+            call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), B, hh, hh,
+                 upin.shape[3], nf, st)
+            self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
+        # ---- encoder, level L-1 .. 0
+        for i in reversed(range(L)):
+            c1, c2 = a["c1_%d" % i], a["c2_%d" % i]
+            h = self.level_in[i]
+            nf = c2.shape[3]
+            dz2, dz1 = g["c2_%d" % i], g["c1_%d" % i]
+            if i < L - 1:
+                dec = L - 2 - i
+                hs = a["up_%d" % dec].shape[1]
+                call("rsu_pool_skip_relu_bwd", _ptr(c2), _ptr(g["pool_%d" % i]), _ptr(g["skip_%d" % dec]), _ptr(dz2), B, h - 4, h - 4, nf, hs, hs, st)
+            self._wgrad("conv_%d/conv2" % i, [(c1, h - 2)], dz2, h - 4)
+            self._bwd_data("conv_%d/conv2" % i, dz2, dz1, h - 2, relu_src=c1)
+            if i > 0:
+                pin = a["pool_%d" % (i - 1)]
+                self._wgrad("conv_%d/conv1" % i, [(pin, h)], dz1, h - 2)
+                self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
+            else:
+                call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
+                     _ptr(self.ws), B, h, h, nf, 1, st)
+                call("rsu_bias_grad", _ptr(dz1), _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B * (h - 2) * (h - 2), nf, st)
+            if self.dilated and i < L - 1:
+                d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
+                dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
+                dec = L - 2 - i
+                hs = a["up_%d" % dec].shape[1]
+                call("rsu_pool_skip_relu_bwd", _ptr(d2), None, _ptr(g["skipd_%d" % dec]), _ptr(dzd2), B, h - 8, h - 8, nf, hs, hs, st)
+                self._wgrad("conv_dilut_%d/atrous_conv2" % i, [(d1, h - 4)], dzd2, h - 8, dil=2)
+                self._bwd_data("conv_dilut_%d/atrous_conv2" % i, dzd2, dzd1, h - 4, relu_src=d1, dil=2)
+                if i > 0:
+                    pin = a["pool_%d" % (i - 1)]
+                    self._wgrad("conv_dilut_%d/atrous_conv1" % i, [(pin, h)], dzd1, h - 4, dil=2)
+                    self._bwd_data("conv_dilut_%d/atrous_conv1" % i, dzd1, g["pool_%d" % (i - 1)], h, accumulate=1, dil=2)
+                else:
+                    call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
+                         _ptr(self.gfirst[1]), _ptr(self.ws), B, h, h, nf, 2, st)
+                    call("rsu_bias_grad", _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B * (h - 4) * (h - 4), nf, st)
+            if i > 0:
+                first_name = ("conv_dilut_%d/atrous_conv1/kernel" if self.dilated else "conv_%d/conv1/kernel") % i
+                self._grads_ready(first_name)
+        # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised:
+        #   dW0[ci][cj] = sum_{t,co} W1[t][cj][co] * gxc[t][ci][co];  db0[cj] = sum_{t,co} W1[t][cj][co] * db1[co]
+        w1 = self.w["conv_0/conv1/kernel"].reshape(9, 3, -1)
+        dw0 = torch.einsum("tjo,tio->ij", w1, self.gfirst[0].reshape(9, 3, -1))
+        db0 = torch.einsum("tjo,o->j", w1, self.g["conv_0/conv1/bias"])
+        if self.dilated and L > 1:
+            wd = self.w["conv_dilut_0/atrous_conv1/kernel"].reshape(9, 3, -1)
+            dw0 = dw0 + torch.einsum("tjo,tio->ij", wd, self.gfirst[1].reshape(9, 3, -1))
+            db0 = db0 + torch.einsum("tjo,o->j", wd, self.g["conv_dilut_0/atrous_conv1/bias"])
+        self.g["color_space_adjust/kernel"].copy_(dw0.view(1, 1, 3, 3))
+        self.g["color_space_adjust/bias"].copy_(db0)
+
+    # ------------------------------------------------------------------ optimizer
+    def learning_rate(self, lr0):
+        """tf.train.exponential_decay(lr, global_step, 1000, 0.95, staircase=True) (tf_aerial_images.py:116-117), float32"""
+        return float(np.float32(lr0) * np.float32(0.95) ** np.float32(self.global_step // 1000))
+
+    def apply_momentum(self, lr0, momentum, gscale=1.0):
+        """MomentumOptimizer step on every live variable (tf_aerial_images.py:120-121), then re-pack bf16 weights."""
+        call("rsu_momentum_step", _ptr(self.flat_w), _ptr(self.flat_acc), _ptr(self.flat_g), self.learning_rate(lr0), momentum, gscale,
+             self.n_live, self._stream())
+        self.global_step += 1
+        self.repack()
+
+
+_DEFAULT_MODELS = {}
+
+
+def forward(X, num_layers, root_size, dilated_layers, dropout_keep=None, params=None):
+    """Drop-in for the reference's unet.forward (unet.py:12): X [B,S,S,3] float32 in [0,1] -> logits [B,P,P,2].
+
+    The reference builds a TF graph and creates its variables on first use; here the variables live in a cached UNet
+    keyed by the static shapes (pass `params` -- a dict of TF-named numpy arrays -- to set them). dropout_keep must be
+    None or 1.0 (the predict path / the final model); see DESIGN.md for dropout."""
+    assert dropout_keep is None or float(dropout_keep) == 1.0, "HIP path implements dropout_keep == 1.0 (identity) only"
+    X = torch.as_tensor(X)
+    B, S = X.shape[0], X.shape[1]
+    assert X.shape[2] == S and X.shape[3] == NUM_CHANNELS
+    P = S - 12 * 2 ** (num_layers - 1) + 8
+    assert input_size_needed(P, num_layers) == S, "input size {} is not a valid U-Net input for {} layers".format(S, num_layers)
+    key = (num_layers, root_size, bool(dilated_layers), B, P)
+    m = _DEFAULT_MODELS.get(key)
+    if m is None:
+        m = _DEFAULT_MODELS[key] = UNet(num_layers, root_size, dilated_layers, B, P, params=params, training=False)
+    elif params is not None:
+        m.load_state_dict(params)
+    m.x.copy_(X.to(m.device, torch.float32))
+    m.forward_device(want_logits=True)
+    return m.logits

@@ -1,0 +1,147 @@
+"""-m gpu: whole-network parity of the HIP path (road_segmentation_unet_amd.UNet over the C ABI) against the CPU oracle
+(oracle/unet_oracle.py) with identical injected weights and inputs.
+
+Two references per case:
+  * oracle with bf16-storage emulation (rounds where the HIP path stores bf16): tight tolerances -- probabilities
+    within 4e-3 absolute, loss within 2e-3 relative, every gradient tensor within 2e-2 relative Frobenius error
+    (bf16 rounding-boundary flips are the only expected differences);
+  * pure float32 oracle (the reference's arithmetic type): the stated fp32 tolerance of the bf16 fast path --
+    probabilities within 3e-2 absolute, loss within 1e-2 relative, gradients within 1e-1 relative Frobenius error
+    (tiny test networks average bf16 noise over very few pixels; at the c1 geometry the measured worst is 1.5e-2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as U  # noqa: E402
+from road_segmentation_unet_amd.unet import UNet, forward, input_size_needed  # noqa: E402
+
+CASES = [
+    # L, root, P, B, dilated
+    (2, 16, 12, 2, False),
+    (3, 16, 20, 2, False),
+    (3, 32, 36, 1, True),
+    (4, 8, 28, 1, True),
+    (3, 16, 188, 1, False),  # BASELINE.json configs[0] (c1) geometry
+]
+
+
+def _setup(L, root, P, B, dilated, seed=3):
+    S = input_size_needed(P, L)
+    rng = np.random.RandomState(seed)
+    X = rng.rand(B, S, S, 3).astype(np.float32)
+    labels = (rng.rand(B, P, P) < 0.2).astype(np.int64)
+    params = U.init_params(L, root, dilated, seed=seed + 1, bias_scale=0.05)
+    return S, X, labels, params
+
+
+def _run_hip(L, root, P, B, dilated, X, labels, params):
+    m = UNet(L, root, dilated, B, P, params=params, training=True)
+    m.x.copy_(torch.from_numpy(X))
+    m.labels.copy_(torch.from_numpy(labels))
+    m.forward_device()
+    m.backward_device(1.0 / (B * P * P))
+    torch.cuda.synchronize()
+    loss = float(m.loss_sum.item()) / (B * P * P)
+    grads = {n: m.g[n].detach().cpu().numpy().copy() for n in m.names}
+    return m, loss, m.prob.detach().cpu().numpy().copy(), grads
+
+
+def _check(loss, prob, grads, ref, ptol, ltol, gtol, tag):
+    rloss, rprob, rgrads = ref
+    assert np.abs(prob - rprob).max() <= ptol, (tag, "prob", float(np.abs(prob - rprob).max()))
+    assert abs(loss - rloss) <= ltol * abs(rloss), (tag, "loss", loss, rloss)
+    worst = ("", 0.0)
+    for n, g in grads.items():
+        r = rgrads[n]
+        scale = float(np.linalg.norm(r.astype(np.float64)))
+        if scale == 0.0:
+            assert not g.any(), (tag, n, "expected zero gradient")
+            continue
+        e = float(np.linalg.norm((g - r).astype(np.float64))) / scale
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] <= gtol, (tag, "grad", worst)
+    return worst
+
+
+@pytest.mark.parametrize("L,root,P,B,dilated", CASES)
+def test_forward_backward_parity(L, root, P, B, dilated):
+    S, X, labels, params = _setup(L, root, P, B, dilated)
+    m, loss, prob, grads = _run_hip(L, root, P, B, dilated, X, labels, params)
+    emu = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=True)
+    w1 = _check(loss, prob, grads, emu, 4e-3, 2e-3, 2e-2, "vs bf16-emulating oracle")
+    f32 = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=False)
+    w2 = _check(loss, prob, grads, f32, 3e-2, 1e-2, 1e-1, "vs float32 oracle")
+    print("worst grad rel err: emu %s %.2e | f32 %s %.2e" % (w1[0], w1[1], w2[0], w2[1]))
+
+
+def test_train_steps_match_oracle():
+    """three fused fwd+bwd+Momentum steps (tf_aerial_images.py:241-244) incl. lr schedule and bf16 re-packing"""
+    L, root, P, B, dilated = 3, 16, 20, 2, True
+    S, X, labels, params = _setup(L, root, P, B, dilated, seed=8)
+    m = UNet(L, root, dilated, B, P, params=params, training=True)
+    ref_p = {k: v.copy() for k, v in params.items()}
+    ref_a = {k: np.zeros_like(v) for k, v in params.items()}
+    rng = np.random.RandomState(0)
+    for step in range(3):
+        Xs = rng.rand(B, S, S, 3).astype(np.float32)
+        ls = (rng.rand(B, P, P) < 0.3).astype(np.int64)
+        m.x.copy_(torch.from_numpy(Xs))
+        m.labels.copy_(torch.from_numpy(ls))
+        m.forward_device()
+        m.backward_device(1.0 / (B * P * P))
+        m.apply_momentum(0.05, 0.9)
+        U.train_step(ref_p, ref_a, Xs, ls, L, root, dilated, lr0=0.05, momentum=0.9, global_step=step, emulate_bf16=True)
+    torch.cuda.synchronize()
+    assert m.global_step == 3
+    sd = m.state_dict()
+    for n in m.names:
+        upd = np.abs(ref_p[n] - params[n]).max()
+        if n.startswith("conv_dilut_%d/" % (L - 1)):
+            np.testing.assert_array_equal(sd[n], params[n])  # dead branch: never updated
+            continue
+        assert upd > 0
+        assert np.abs(sd[n] - ref_p[n]).max() <= 0.03 * upd + 1e-7, (n, float(np.abs(sd[n] - ref_p[n]).max()), float(upd))
+
+
+def test_forward_function_matches_reference_signature():
+    """unet.forward(X, num_layers, root_size, dilated_layers, dropout_keep) -> logits [B,P,P,2]"""
+    L, root, P, B = 3, 16, 20, 1
+    S, X, labels, params = _setup(L, root, P, B, False, seed=12)
+    logits = forward(X, L, root, False, dropout_keep=None, params=params)
+    assert tuple(logits.shape) == (B, P, P, 2)
+    ref, _ = U.forward(params, X, L, root, False, emulate_bf16=True)
+    assert np.abs(logits.cpu().numpy() - ref).max() <= 2e-2 * max(1.0, float(np.abs(ref).max()))
+    with pytest.raises(AssertionError):
+        forward(np.zeros((1, 61, 61, 3), np.float32), L, root, False)
+
+
+def test_linearity_property_full_size_layer():
+    """size-independent property at a BASELINE config-2 layer shape (too big for the oracle in seconds):
+    conv(x1 + x2) == conv(x1) + conv(x2) without bias/ReLU. Inputs are small integers so x1 + x2 is exact in bf16;
+    what remains is the three bf16 output roundings: |lhs - rhs| <= 2^-8 (|lhs| + |o1| + |o2|) + 1e-3."""
+    from tests import hiputil as hu
+    from road_segmentation_unet_amd._lib import RsuSrc, call
+    rng = np.random.RandomState(1)
+    N, H, C = 1, 282, 128   # level-1 conv2 of config 2: [B,282,282,128] -> [B,280,280,128]
+    x1 = rng.randint(-8, 9, size=(N, H, H, C)).astype(np.float32)
+    x2 = rng.randint(-8, 9, size=(N, H, H, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, C)) / np.sqrt(9 * C) / 8).astype(np.float32)
+    wp = hu.pack_conv_fwd(w)
+    outs = []
+    keep = []
+    for x in (x1, x2, x1 + x2):
+        xd = hu.dev_bf16(x)
+        assert bool((xd.float().cpu() == torch.from_numpy(x)).all())  # exactly representable
+        y = torch.zeros((N, H - 2, H - 2, C), dtype=torch.bfloat16, device=hu.DEV)
+        s = (RsuSrc * 1)(hu.src_of(xd, H, H))
+        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), None, hu.ptr(y), N, H, H, C, 1, 0, hu.stream())
+        keep.append(xd)
+        outs.append(y.float())
+    torch.cuda.synchronize()
+    lhs, rhs = outs[2], outs[0] + outs[1]
+    tol = 2.0 ** -8 * (lhs.abs() + outs[0].abs() + outs[1].abs()) + 1e-3
+    assert float(outs[0].abs().max()) > 0.5
+    assert bool(((lhs - rhs).abs() <= tol).all())

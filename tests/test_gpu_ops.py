@@ -1,0 +1,336 @@
+"""-m gpu: op-level parity of the HIP kernels, called through the C ABI (include/rsu.h), against the CPU oracle on the
+same seeded, bf16-rounded inputs. Tolerances (stated in hiputil.assert_bf16_close): 1 bfloat16 ulp relative (2^-7)
++ 2e-5*max|ref| for bf16 outputs; rtol 1e-4 (+1e-5*max|ref|) for float32 outputs accumulated from bf16 data."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tiler_oracle as T  # noqa: E402
+from oracle import unet_oracle as U  # noqa: E402
+from tests import hiputil as hu  # noqa: E402
+from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------- conv forward
+CONV_SHAPES = [
+    # N, H, W, Cin, Cout, dil
+    (1, 12, 12, 32, 64, 1),
+    (2, 37, 41, 64, 64, 1),
+    (1, 30, 30, 16, 16, 1),
+    (1, 40, 36, 96, 128, 2),
+    (1, 70, 75, 64, 192, 1),
+    (2, 20, 20, 128, 256, 1),
+    (1, 150, 140, 64, 64, 1),
+    (1, 26, 26, 256, 128, 2),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", CONV_SHAPES)
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv2d_fwd(N, H, W, Cin, Cout, dil, relu):
+    rng = np.random.RandomState(Cin * 7 + Cout + H)
+    x = hu.q(_rand(rng, N, H, W, Cin))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    xd = hu.dev_bf16(x)
+    wp = hu.pack_conv_fwd(w)
+    bd = hu.dev_f32(b)
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    s = (RsuSrc * 1)(hu.src_of(xd, H, W))
+    call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, dil, relu, hu.stream())
+    ref = U.conv2d_fwd(x, hu.q(w), b, dil=dil, relu=bool(relu))
+    hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd")
+
+
+def test_conv2d_fwd_three_cropped_sources():
+    """virtual crop+concat of unet.py:70-85: [skip (cropped), dilated skip (cropped), up]"""
+    rng = np.random.RandomState(5)
+    N, h, w = 2, 22, 26
+    a = hu.q(_rand(rng, N, 34, 38, 32))
+    bsrc = hu.q(_rand(rng, N, 28, 30, 32))
+    c = hu.q(_rand(rng, N, h, w, 32))
+    W = _rand(rng, 3, 3, 96, 64, scale=0.05)
+    bias = _rand(rng, 64, scale=0.1)
+    ad, bd_, cd = hu.dev_bf16(a), hu.dev_bf16(bsrc), hu.dev_bf16(c)
+    wp = hu.pack_conv_fwd(W, [32, 32, 32])
+    y = torch.zeros((N, h - 2, w - 2, 64), dtype=torch.bfloat16, device=hu.DEV)
+    srcs = (RsuSrc * 3)(hu.src_of(ad, h, w), hu.src_of(bd_, h, w), hu.src_of(cd, h, w))
+    biasd = hu.dev_f32(bias)
+    call("rsu_conv2d_fwd", srcs, 3, hu.ptr(wp), hu.ptr(biasd), hu.ptr(y), N, h, w, 64, 1, 1, hu.stream())
+    cat = np.concatenate([U.center_crop(a, h, w), U.center_crop(bsrc, h, w), c], axis=3)
+    ref = U.conv2d_fwd(cat, hu.q(W), bias, relu=True)
+    hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd 3 sources")
+
+
+def test_conv2d_fwd_odd_channel_segments():
+    """channel counts that are multiples of 8 but not of 32 (root_size 16 / 8 networks): K segments are zero-padded"""
+    rng = np.random.RandomState(6)
+    N, h = 1, 18
+    a, c = hu.q(_rand(rng, N, 24, 24, 16)), hu.q(_rand(rng, N, h, h, 16))
+    W = _rand(rng, 3, 3, 32, 16, scale=0.1)
+    wp = hu.pack_conv_fwd(W, [16, 16])
+    y = torch.zeros((N, h - 2, h - 2, 16), dtype=torch.bfloat16, device=hu.DEV)
+    ad, cd = hu.dev_bf16(a), hu.dev_bf16(c)
+    srcs = (RsuSrc * 2)(hu.src_of(ad, h, h), hu.src_of(cd, h, h))
+    call("rsu_conv2d_fwd", srcs, 2, hu.ptr(wp), None, hu.ptr(y), N, h, h, 16, 1, 1, hu.stream())
+    ref = U.conv2d_fwd(np.concatenate([U.center_crop(a, h, h), c], axis=3), hu.q(W), None, relu=True)
+    hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd 16+16")
+
+
+# ------------------------------------------------------------------------------------------- conv backward data
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", CONV_SHAPES[:6])
+def test_conv2d_bwd_data(N, H, W, Cin, Cout, dil):
+    rng = np.random.RandomState(Cin + Cout * 3 + W)
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    dz = hu.q(_rand(rng, N, Ho, Wo, Cout))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cout))
+    yprev = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
+    wp = hu.pack_conv_bwd(w)
+    dzd, yd = hu.dev_bf16(dz), hu.dev_bf16(yprev)
+    dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), hu.ptr(yd), 0, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    ref = U.relu_bwd(yprev, U.conv2d_bwd_data(dz, hu.q(w), (H, W), dil=dil))
+    hu.assert_bf16_close(hu.host(dx), ref, "conv2d_bwd_data+relu mask")
+    # no mask, then accumulate a second time: dx = q(q(g) + g)
+    dx2 = torch.zeros((N, H, W, Cin), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 0, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    g = U.conv2d_bwd_data(dz, hu.q(w), (H, W), dil=dil)
+    hu.assert_bf16_close(hu.host(dx2), g, "conv2d_bwd_data")
+    first = hu.host(dx2).copy()
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 1, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    hu.assert_bf16_close(hu.host(dx2), first + g, "conv2d_bwd_data accumulate", ulps=2.0)
+
+
+def test_conv2d_bwd_data_source_slice():
+    """backward towards one concat source: its own weight pack (rows ci_off..ci_off+cnt of the kernel)"""
+    rng = np.random.RandomState(9)
+    N, H, Cin, Cout = 1, 20, 48, 32
+    dz = hu.q(_rand(rng, N, H - 2, H - 2, Cout))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=0.1)
+    full = U.conv2d_bwd_data(dz, hu.q(w), (H, H))
+    for off, cnt in [(0, 16), (16, 16), (32, 16)]:
+        wp = hu.pack_conv_bwd(w, off, cnt)
+        dx = torch.zeros((N, H, H, cnt), dtype=torch.bfloat16, device=hu.DEV)
+        dzd = hu.dev_bf16(dz)
+        call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), None, 0, N, H, H, cnt, 0, cnt, Cout, 1, hu.stream())
+        hu.assert_bf16_close(hu.host(dx), full[..., off:off + cnt], "bwd_data slice %d" % off)
+
+
+# ------------------------------------------------------------------------------------------- conv backward weight
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", CONV_SHAPES)
+def test_conv2d_bwd_weight_and_bias(N, H, W, Cin, Cout, dil):
+    rng = np.random.RandomState(Cin * 3 + Cout + H)
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    x = hu.q(_rand(rng, N, H, W, Cin))
+    dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
+    xd, dzd = hu.dev_bf16(x), hu.dev_bf16(dz)
+    dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+    db = torch.zeros(Cout, dtype=torch.float32, device=hu.DEV)
+    ws = torch.zeros(max(lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout), lib().rsu_bias_grad_ws_floats(N * Ho * Wo, Cout)),
+                     dtype=torch.float32, device=hu.DEV)
+    s = hu.src_of(xd, H, W)
+    call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
+    ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=dil)
+    hu.assert_f32_close(hu.host(dw), ref_dw, "conv2d_bwd_weight")
+    if 256 % (Cout // 8) == 0:
+        call("rsu_bias_grad", hu.ptr(dzd), hu.ptr(db), hu.ptr(ws), N * Ho * Wo, Cout, hu.stream())
+        hu.assert_f32_close(hu.host(db), ref_db, "bias_grad")
+
+
+def test_conv2d_bwd_weight_cropped_sources():
+    rng = np.random.RandomState(10)
+    N, h = 2, 24
+    a, c = hu.q(_rand(rng, N, 36, 36, 32)), hu.q(_rand(rng, N, h, h, 64))
+    dz = hu.q(_rand(rng, N, h - 2, h - 2, 64, scale=0.1))
+    ad, cd, dzd = hu.dev_bf16(a), hu.dev_bf16(c), hu.dev_bf16(dz)
+    dw = torch.zeros((3, 3, 96, 64), dtype=torch.float32, device=hu.DEV)
+    ws = torch.zeros(lib().rsu_conv2d_bwd_weight_ws_floats(96, 32, 64), dtype=torch.float32, device=hu.DEV)
+    for t, off in [(ad, 0), (cd, 32)]:
+        s = hu.src_of(t, h, h)
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(ws), N, h - 2, h - 2, 96, off, 64, 1, hu.stream())
+    cat = np.concatenate([U.center_crop(a, h, h), c], axis=3)
+    hu.assert_f32_close(hu.host(dw), U.conv2d_bwd_weight(cat, dz)[0], "bwd_weight 2 cropped sources")
+
+
+# ------------------------------------------------------------------------------------------- first layer
+@pytest.mark.parametrize("dil", [1, 2])
+def test_color_adjust_and_first_conv(dil):
+    rng = np.random.RandomState(11 + dil)
+    N, H, W, Cout = 2, 29, 35, 64
+    x = rng.rand(N, H, W, 3).astype(np.float32)
+    w0 = _rand(rng, 3, 3, scale=0.5)
+    b0 = _rand(rng, 3, scale=0.1)
+    w1 = _rand(rng, 3, 3, 3, Cout, scale=0.3)
+    b1 = _rand(rng, Cout, scale=0.1)
+    in16 = torch.zeros((N, H, W, 16), dtype=torch.bfloat16, device=hu.DEV)
+    xd_, w0d, b0d, w1d, b1d = hu.dev_f32(x), hu.dev_f32(w0), hu.dev_f32(b0), hu.dev_f32(w1), hu.dev_f32(b1)  # keep alive
+    call("rsu_color_adjust_fwd", hu.ptr(xd_), hu.ptr(w0d), hu.ptr(b0d), hu.ptr(in16), N * H * W, hu.stream())
+    got16 = hu.host(in16)
+    net0 = U.conv1x1_fwd(x, w0, b0, sub=0.5)
+    hu.assert_bf16_close(got16[..., 0:3], net0, "color_adjust net0")
+    hu.assert_bf16_close(got16[..., 4:7], x - 0.5, "color_adjust xc")
+    assert not got16[..., 3].any() and not got16[..., 7:].any()
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(w1d), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, hu.stream())
+    ref = U.conv2d_fwd(got16[..., 0:3], w1, b1, dil=dil)  # fp32 weights on purpose: VALU kernel
+    hu.assert_bf16_close(hu.host(y), ref, "conv_first_fwd")
+    # weight gradients (MFMA narrow wgrad over the 16-channel tensor)
+    dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
+    dw1 = torch.zeros((3, 3, 3, Cout), dtype=torch.float32, device=hu.DEV)
+    gxc = torch.zeros((3, 3, 3, Cout), dtype=torch.float32, device=hu.DEV)
+    ws = torch.zeros(lib().rsu_conv_first_bwd_ws_floats(Cout), dtype=torch.float32, device=hu.DEV)
+    dzd = hu.dev_bf16(dz)
+    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gxc), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
+    hu.assert_f32_close(hu.host(dw1), U.conv2d_bwd_weight(got16[..., 0:3], dz, dil=dil)[0], "conv_first dW")
+    hu.assert_f32_close(hu.host(gxc), U.conv2d_bwd_weight(got16[..., 4:7], dz, dil=dil)[0], "conv_first gxc")
+
+
+# ------------------------------------------------------------------------------------------- pool
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 16, 64), (1, 30, 26, 16), (1, 9, 11, 8)])
+def test_maxpool_fwd_and_junction_bwd(N, H, W, C):
+    rng = np.random.RandomState(H + C)
+    x = hu.q(np.maximum(_rand(rng, N, H, W, C), 0))
+    x[0, :4, :4, :] = x[0, 0, 0, :]  # force ties (incl. zeros) in a corner
+    xd = hu.dev_bf16(x)
+    y = torch.zeros((N, H // 2, W // 2, C), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_maxpool2x2_fwd", hu.ptr(xd), hu.ptr(y), N, H, W, C, hu.stream())
+    np.testing.assert_array_equal(hu.host(y), U.maxpool_fwd(x))
+    Hs, Ws = H - 4, W - 6
+    dpool = hu.q(_rand(rng, N, H // 2, W // 2, C))
+    dskip = hu.q(_rand(rng, N, Hs, Ws, C))
+    dpd, dsd = hu.dev_bf16(dpool), hu.dev_bf16(dskip)
+    for use_pool, use_skip in [(1, 1), (1, 0), (0, 1)]:
+        dz = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        call("rsu_pool_skip_relu_bwd", hu.ptr(xd), hu.ptr(dpd) if use_pool else None,
+             hu.ptr(dsd) if use_skip else None, hu.ptr(dz), N, H, W, C, Hs, Ws, hu.stream())
+        g = np.zeros_like(x)
+        if use_pool:
+            xe = x[:, :H // 2 * 2, :W // 2 * 2]
+            g[:, :H // 2 * 2, :W // 2 * 2] += U.maxpool_bwd(xe, dpool)
+        if use_skip:
+            g += U.center_pad_like(dskip, x.shape)
+        ref = U.relu_bwd(x, g)
+        hu.assert_bf16_close(hu.host(dz), ref, "pool_skip_relu_bwd pool=%d skip=%d" % (use_pool, use_skip))
+
+
+# ------------------------------------------------------------------------------------------- transposed conv
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 7, 9, 128, 64), (1, 14, 14, 64, 32), (1, 26, 24, 32, 16), (1, 28, 28, 256, 128)])
+def test_convT(N, H, W, Cin, Cout):
+    rng = np.random.RandomState(Cin + H)
+    x = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
+    K = _rand(rng, 2, 2, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    seg = (ctypes.c_int * 1)(Cin)
+    pf = torch.zeros(4 * lib().rsu_packed_bytes(1, Cout, seg, 1) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    seg2 = (ctypes.c_int * 1)(Cout)
+    pb = torch.zeros(lib().rsu_packed_bytes(4, Cin, seg2, 1) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    Kd = hu.dev_f32(K)
+    call("rsu_pack_convT_fwd", hu.ptr(Kd), hu.ptr(pf), Cin, Cout, hu.stream())
+    call("rsu_pack_convT_bwd", hu.ptr(Kd), hu.ptr(pb), Cin, Cout, hu.stream())
+    xd = hu.dev_bf16(x)
+    y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    bd = hu.dev_f32(b)
+    call("rsu_convT2x2_fwd", hu.ptr(xd), hu.ptr(pf), hu.ptr(bd), hu.ptr(y), N, H, W, Cin, Cout, hu.stream())
+    hu.assert_bf16_close(hu.host(y), U.convT_fwd(x, hu.q(K), b), "convT fwd")
+    dy = hu.q(_rand(rng, N, 2 * H, 2 * W, Cout, scale=0.1))
+    dyd = hu.dev_bf16(dy)
+    dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xd), N, H, W, Cin, Cout, hu.stream())
+    rdx, rdK, rdb = U.convT_bwd(x, hu.q(K), dy)
+    hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx), "convT bwd_data")
+    dK = torch.full((2, 2, Cout, Cin), float("nan"), dtype=torch.float32, device=hu.DEV)
+    ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(Cin, Cout), dtype=torch.float32, device=hu.DEV)
+    call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(ws), N, H, W, Cin, Cout, hu.stream())
+    hu.assert_f32_close(hu.host(dK), rdK, "convT bwd_weight")
+
+
+# ------------------------------------------------------------------------------------------- head, optimizer
+@pytest.mark.parametrize("C", [64, 16])
+def test_head(C):
+    rng = np.random.RandomState(C)
+    npix = 3 * 37 * 41
+    act = hu.q(np.maximum(_rand(rng, npix, C), 0))
+    w = _rand(rng, C, 2, scale=0.3)
+    b = _rand(rng, 2, scale=0.1)
+    labels = (rng.rand(npix) < 0.2).astype(np.int64)
+    ad, wd, bd = hu.dev_bf16(act), hu.dev_f32(w), hu.dev_f32(b)
+    prob = torch.zeros(npix, dtype=torch.float32, device=hu.DEV)
+    logits = torch.zeros((npix, 2), dtype=torch.float32, device=hu.DEV)
+    call("rsu_head_fwd", hu.ptr(ad), hu.ptr(wd), hu.ptr(bd), hu.ptr(prob), hu.ptr(logits), npix, C, hu.stream())
+    ref_logits = U.conv1x1_fwd(act, w, b)
+    rp, rloss, rdl = U.softmax_ce(ref_logits, labels)
+    hu.assert_f32_close(hu.host(logits), ref_logits, "head logits", rtol=1e-5)
+    hu.assert_f32_close(hu.host(prob), rp, "head prob", rtol=1e-4, atol_scale=1e-6)
+    inv = 1.0 / (2 * npix)  # as if this rank held half of the global batch
+    dact = torch.zeros((npix, C), dtype=torch.bfloat16, device=hu.DEV)
+    dw = torch.zeros((C, 2), dtype=torch.float32, device=hu.DEV)
+    db = torch.zeros(2, dtype=torch.float32, device=hu.DEV)
+    loss = torch.zeros(1, dtype=torch.float32, device=hu.DEV)
+    ws = torch.zeros(lib().rsu_head_ws_floats(npix, C), dtype=torch.float32, device=hu.DEV)
+    lab = torch.from_numpy(labels).to(hu.DEV)
+    call("rsu_head_fwd_bwd", hu.ptr(ad), hu.ptr(wd), hu.ptr(bd), hu.ptr(lab), hu.ptr(prob), hu.ptr(loss), hu.ptr(dact), hu.ptr(dw), hu.ptr(db),
+         hu.ptr(ws), npix, C, inv, hu.stream())
+    rdl = rdl * 0.5  # oracle's dlogits are /npix; this call scales by 1/(2 npix)
+    rdx, rdw, rdb = U.conv1x1_bwd(act, w, rdl)
+    assert abs(float(hu.host(loss)[0]) / npix - rloss) < 2e-5 * max(1.0, abs(rloss))
+    hu.assert_bf16_close(hu.host(dact), U.relu_bwd(act, rdx), "head dact")
+    hu.assert_f32_close(hu.host(dw), rdw, "head dw")
+    hu.assert_f32_close(hu.host(db), rdb, "head db")
+
+
+def test_momentum_step():
+    rng = np.random.RandomState(3)
+    n = 1003
+    w, a, g = _rand(rng, n), _rand(rng, n), _rand(rng, n)
+    wd, ad, gd = torch.zeros(1004, device=hu.DEV), torch.zeros(1004, device=hu.DEV), torch.zeros(1004, device=hu.DEV)
+    wd[:n], ad[:n], gd[:n] = hu.dev_f32(w), hu.dev_f32(a), hu.dev_f32(g)
+    call("rsu_momentum_step", hu.ptr(wd), hu.ptr(ad), hu.ptr(gd), 0.01, 0.9, 1.0, n, hu.stream())
+    U.momentum_step(w, a, g, 0.01, 0.9)
+    np.testing.assert_allclose(hu.host(ad)[:n], a, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(hu.host(wd)[:n], w, rtol=1e-6, atol=1e-7)
+    assert float(hu.host(wd)[n]) == 0.0
+
+
+# ------------------------------------------------------------------------------------------- tiler
+@pytest.mark.parametrize("H,P,S,stride,nimg", [(20, 8, 12, 4, 2), (44, 20, 60, 12, 3), (16, 16, 24, 16, 1)])
+def test_tiler_extract_and_overlap(H, P, S, stride, nimg):
+    rng = np.random.RandomState(H)
+    imgs = rng.rand(nimg, H, H, 3).astype(np.float32)
+    pps = (H - P) // stride + 1
+    nt = nimg * pps * pps
+    tiles = torch.zeros((nt, S, S, 3), dtype=torch.float32, device=hu.DEV)
+    idev = hu.dev_f32(imgs)
+    half = nt // 2
+    if half:
+        call("rsu_extract_tiles", hu.ptr(idev), hu.ptr(tiles), nimg, H, S, P, stride, 0, half, hu.stream())
+    call("rsu_extract_tiles", hu.ptr(idev), hu.ptr(tiles[half:]), nimg, H, S, P, stride, half, nt - half, hu.stream())
+    ref = T.extract_patches(T.mirror_border(imgs, (S - P) // 2), S, stride=stride, predict_patch_size=P)
+    np.testing.assert_array_equal(hu.host(tiles), ref.astype(np.float32))  # bit-exact: pure data movement
+    prob = rng.rand(nt, P, P).astype(np.float32)
+    acc = torch.zeros((nimg, H, H), dtype=torch.float32, device=hu.DEV)
+    hits = torch.zeros((nimg, H, H), dtype=torch.float32, device=hu.DEV)
+    pdev = hu.dev_f32(prob)
+    if half:
+        call("rsu_overlap_add", hu.ptr(pdev), hu.ptr(acc), hu.ptr(hits), nimg, H, P, stride, 0, half, hu.stream())
+    call("rsu_overlap_add", hu.ptr(pdev[half:]), hu.ptr(acc), hu.ptr(hits), nimg, H, P, stride, half, nt - half, hu.stream())
+    out = torch.zeros_like(acc)
+    call("rsu_overlap_finish", hu.ptr(acc), hu.ptr(hits), hu.ptr(out), acc.numel(), hu.stream())
+    refm = T.images_from_patches(prob.astype(np.float64).reshape(nimg, pps * pps, P, P, 1), stride=stride)[..., 0]
+    np.testing.assert_allclose(hu.host(out), refm, rtol=2e-6, atol=1e-7)
+
+
+def test_abi_rejects_bad_geometry():
+    """error behaviour: the reference asserts (unet.py:108, images.py:60-61); the ABI returns RSU_EINVAL"""
+    o = ctypes.c_int()
+    assert lib().rsu_input_size_needed(128, 5, ctypes.byref(o)) == -22
+    assert lib().rsu_extract_tiles(None, None, 1, 20, 12, 8, 5, 0, 1, None) == -22
