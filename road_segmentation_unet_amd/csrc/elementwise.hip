@@ -212,14 +212,22 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const bf16_t* __restrict
         partial[(long)blockIdx.x * C + c] = t;
     }
 }
-// C may exceed 256: handled by launching with blockDim = 256 and looping channels in the second stage only;
-// the first stage requires C <= 2048 and (C/8) | 256, checked by the host.
-__global__ void k_colsum_final(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// second stage: 32 channels x 8 partial-lanes per block, LDS tree over the lanes (fixed order: deterministic)
+__global__ void __launch_bounds__(256) k_colsum_final(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    __shared__ float red[256];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += partial[(long)b * C + c];
-    out[c] = t;
+    if (c < C)
+        for (int b = part; b < nblk; b += 8) t += partial[(long)b * C + c];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r += red[q * 32 + cl];
+        out[c] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -239,6 +247,33 @@ __global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         for (int z = 0; z < nsplit; ++z) t += *(const f32x4*)(slab + z * slab_elems + e);
         *(f32x4*)(out + e) = t;
+    }
+}
+// many splits, few outputs: 32 float4 outputs x 8 split-lanes per block, fixed-order LDS tree
+__global__ void __launch_bounds__(256) k_reduce_slabs_wide(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntap,
+                                                           int CsOut, int cs_off, int cs_cnt, int CfOut) {
+    __shared__ f32x4 red[256];
+    const int cf4 = CfOut >> 2;
+    const long total = (long)ntap * cs_cnt * cf4;
+    const long slab_elems = (long)ntap * CsOut * CfOut;
+    const int el = threadIdx.x & 31, zp = threadIdx.x >> 5;
+    const long tid = (long)blockIdx.x * 32 + el;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    long e = 0;
+    if (tid < total) {
+        const int c4 = (int)(tid % cf4);
+        long r = tid / cf4;
+        const int cs = (int)(r % cs_cnt), tap = (int)(r / cs_cnt);
+        e = ((long)tap * CsOut + cs_off + cs) * CfOut + c4 * 4;
+        for (int z = zp; z < nsplit; z += 8) t += *(const f32x4*)(slab + z * slab_elems + e);
+    }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (zp == 0 && tid < total) {
+        f32x4 r = red[el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r += red[q * 32 + el];
+        *(f32x4*)(out + e) = r;
     }
 }
 
@@ -346,16 +381,25 @@ __global__ void __launch_bounds__(256) k_head(const bf16_t* __restrict__ act, co
 template __global__ void k_head<true>(const bf16_t*, const float*, const float*, const int64_t*, float*, float*, bf16_t*, float*, long, int, float);
 template __global__ void k_head<false>(const bf16_t*, const float*, const float*, const int64_t*, float*, float*, bf16_t*, float*, long, int, float);
 
-__global__ void k_head_final(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ loss_sum,
-                             int nblk, int C) {
+__global__ void __launch_bounds__(256) k_head_final(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
+                                                    float* __restrict__ loss_sum, int nblk, int C) {
+    __shared__ float red[256];
     const int nout = 2 * C + 3;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= nout) return;
+    const int ol = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int o = blockIdx.x * 32 + ol;
     float t = 0.f;
-    for (int bk = 0; bk < nblk; ++bk) t += partial[(long)bk * nout + o];
-    if (o < 2 * C) dw[o] = t;
-    else if (o < 2 * C + 2) db[o - 2 * C] = t;
-    else loss_sum[0] += t;
+    if (o < nout)
+        for (int bk = part; bk < nblk; bk += 8) t += partial[(long)bk * nout + o];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (part == 0 && o < nout) {
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r += red[q * 32 + ol];
+        if (o < 2 * C) dw[o] = r;
+        else if (o < 2 * C + 2) db[o - 2 * C] = r;
+        else loss_sum[0] += r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,20 +558,24 @@ hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void
 int ew_colsum_blocks(long npix, int C) {
     const int lanes_p = 256 / (C / 8);
     long nb = (npix + (long)lanes_p * 64 - 1) / ((long)lanes_p * 64);
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
 hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st) {
     const int nb = ew_colsum_blocks(npix, C);
     hipLaunchKernelGGL(k_colsum_partial, dim3(nb), dim3(256), 0, st, (const bf16_t*)dz, ws, npix, C);
-    hipLaunchKernelGGL(k_colsum_final, dim3((C + 255) / 256), dim3(256), 0, st, ws, db, nb, C);
+    hipLaunchKernelGGL(k_colsum_final, dim3((C + 31) / 32), dim3(256), 0, st, ws, db, nb, C);
     return hipGetLastError();
 }
 hipError_t ew_reduce_slabs(const float* slab, float* out, int nsplit, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut,
                            hipStream_t st) {
     const long total = (long)ntap * cs_cnt * (CfOut / 4);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off, cs_cnt, CfOut);
+    if (nsplit >= 16 && (total + 31) / 32 < 0x7fffffffL)
+        hipLaunchKernelGGL(k_reduce_slabs_wide, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off,
+                           cs_cnt, CfOut);
+    else
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off, cs_cnt, CfOut);
     return hipGetLastError();
 }
 int ew_head_blocks(long npix, int C) {
@@ -542,7 +590,7 @@ hipError_t ew_head(bool train, const void* act, const float* w, const float* b, 
     const int nb = ew_head_blocks(npix, C);
     if (train) {
         hipLaunchKernelGGL(k_head<true>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, labels, prob, logits, (bf16_t*)dact, ws, npix, C, inv_count);
-        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 255) / 256), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
+        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 31) / 32), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
     } else {
         hipLaunchKernelGGL(k_head<false>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, nullptr, prob, logits, nullptr, nullptr, npix, C, 0.f);
     }

@@ -43,6 +43,12 @@ enum { IGF_CFG_64x256 = 0, IGF_CFG_128x256 = 1, IGF_CFG_128x128 = 2, IGF_CFG_128
 struct IgFwdCfgInfo { int TN, TM, threads; };
 IgFwdCfgInfo igemm_fwd_cfg_info(int cfg);
 size_t igemm_fwd_lds_bytes(int cfg, int ntap, int npix_max);
+// second generation (persistent, counted-vmcnt pipeline; igemm_fwd2.hip)
+enum { IGF2_CFG_128x256 = 0, IGF2_CFG_64x512 = 1, IGF2_CFG_128x128 = 2, IGF2_CFG_64x256 = 3, IGF2_NCFG = 4 };
+IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg);
+int igemm_fwd2_max_pieces(int cfg);
+size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max);
+hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 // ntap in {1,4,9}
 hipError_t igemm_fwd_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 

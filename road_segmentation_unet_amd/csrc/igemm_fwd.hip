@@ -17,8 +17,11 @@
 // global->LDS traffic is LDS-DMA issued one stage ahead; one __syncthreads() per stage.
 #include "igemm.h"
 
+// occupancy target: the register-hungry shapes run one workgroup per CU, the others two (tells the scheduler not to
+// serialise the fragment prefetch to save registers)
 template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS>
-__global__ void __launch_bounds__(WCO* WPX * 64) igemm_fwd_kernel(const IgFwdParams p) {
+__global__ void __launch_bounds__(WCO* WPX * 64) __attribute__((amdgpu_waves_per_eu(1, (CT * PT > 16 ? 1 : 2))))
+igemm_fwd_kernel(const IgFwdParams p) {
     constexpr int NW = WCO * WPX;
     constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
     constexpr int WT = TN / 16;  // weight tiles per tap held in LDS
@@ -138,12 +141,13 @@ __global__ void __launch_bounds__(WCO* WPX * 64) igemm_fwd_kernel(const IgFwdPar
         }
         const int wb = (s & 1) * WBUF;
         const int ab = a_base + (chunk & 1) * ABUF;
-#pragma unroll
-        for (int tl = 0; tl < TPS; ++tl) {
+        // software pipeline over the taps of this stage: the fragments of tap tl+1 are requested from LDS
+        // before the MFMAs of tap tl are issued (two register sets, statically indexed after unrolling)
+        bf16x8 fa[2][CT], fb[2][PT];
+        auto load_tap = [&](int tl, bf16x8(&a)[CT], bf16x8(&b)[PT]) {
             const int tap = tg * TPS + tl;
             const int ky = tap / KW, kx = tap - ky * KW;
             const int toff = (ky * CW + kx) * p.dil;
-            bf16x8 a[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 a[ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + wb + ((tl * WT + wco * CT + ct) * 64 + lane) * 16);
@@ -151,11 +155,19 @@ __global__ void __launch_bounds__(WCO* WPX * 64) igemm_fwd_kernel(const IgFwdPar
             for (int pt = 0; pt < PT; ++pt) {
                 const int hp = hpb[pt] + toff;
                 const int off = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);
-                const bf16x8 b = *(const __attribute__((address_space(3))) bf16x8*)(lds + ab + off);
+                b[pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + ab + off);
+            }
+        };
+        load_tap(0, fa[0], fb[0]);
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) {
+            if (tl + 1 < TPS) load_tap(tl + 1, fa[(tl + 1) & 1], fb[(tl + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tap's MFMAs
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct], b, acc[ct][pt], 0, 0, 0);
-            }
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tl & 1][ct], fb[tl & 1][pt], acc[ct][pt], 0, 0, 0);
         }
         __syncthreads();
     }

@@ -1,0 +1,395 @@
+// igemm_fwd2: persistent, deeply pipelined version of the NHWC bf16 implicit-GEMM convolution (see igemm_fwd.hip for
+// the data layout: fragment-ordered weights, pixel-major swizzled halo tile, channel-permuted 16-byte stores).
+//
+// What changes against igemm_fwd:
+//   * one workgroup per CU walks a list of output tiles; the (chunk, tap-group) STAGE STREAM runs continuously across
+//     tile boundaries, so the first stages of the next tile are already in flight while the current tile finishes
+//     (no exposed prologue, the epilogue is the only per-tile bubble);
+//   * weights are prefetched TWO stages ahead into a 3-slot LDS ring, the halo tile of the next chunk one chunk
+//     ahead into a 2-slot ring; nothing ever drains: each wave waits with a COUNTED s_waitcnt vmcnt(N) for exactly
+//     the LDS-DMA loads its next stage needs, then one raw s_barrier per stage publishes everybody's pieces;
+//   * every wave issues a CONSTANT number of LDS-DMA instructions per stage position (halo pieces are padded with
+//     loads of the zero page into a scratch slot), which is what makes N an immediate;
+//   * epilogue stores go through a buffer descriptor with out-of-range offsets for masked lanes: always the same
+//     number of VMEM instructions per tile, so the counters stay exact across tiles (CDNA4 vmcnt counts stores too).
+#include <type_traits>
+
+#include "igemm.h"
+
+#define RSU_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int SPC, int WPS, int NA>
+__device__ __forceinline__ constexpr int vm_allowed(int j) {
+    // loads that may still be in flight when stage position j starts (issue order: see the kernel body)
+    return SPC == 1 ? WPS : (j == 0 ? WPS : WPS + NA);
+}
+
+template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) igemm_fwd2_kernel(const IgFwdParams p) {
+    constexpr int NW = 4;
+    static_assert(WCO * WPX == NW, "four waves");
+    constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
+    constexpr int WT = TN / 16;
+    constexpr int SPC = NTAP / TPS;
+    constexpr int WBUF = TPS * WT * 1024;
+    constexpr int NWB = 3;                     // weight ring slots (prefetch distance 2)
+    constexpr int WPS = TPS * WT / NW;         // weight DMA instructions per wave per stage
+    constexpr int KH = NTAP / KW;
+    static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && (TPS * WT) % NW == 0, "bad config");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+    const int ABUF = p.g.npix_max * 64;
+    const int a_base = NWB * WBUF;
+    const int dummy_base = a_base + 2 * ABUF;  // 1 KiB scratch slot for padding loads
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wco = wave / WPX, wpx = wave % WPX;
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int SW = p.g.SW, CW = p.g.CW;
+    const int ph = blockIdx.y;
+    const bf16_t* wp = p.wp + (long)ph * p.wp_y_stride;
+    const int ooffy = ph >> 1, ooffx = ph & 1;
+
+    // ---- this workgroup's tile list: fixed channel block, m-tiles first, first+stride, ...
+    const int cob = blockIdx.x % p.ncob;
+    const int tile0 = blockIdx.x / p.ncob, tstride = gridDim.x / p.ncob;
+    const int tpi = p.g.nstrips * p.g.tiles_per_strip;
+    const int ntile_m = p.N * tpi;
+    const int my_tiles = tile0 < ntile_m ? (ntile_m - tile0 + tstride - 1) / tstride : 0;
+    if (my_tiles == 0) return;
+    const int nchunks = p.nchunk[0] + p.nchunk[1] + p.nchunk[2];
+    const int GC = my_tiles * nchunks;  // chunks in this workgroup's stream
+
+    struct Tile { int n, x0, sw, m0, y_first, iy0, ix0, npix; };
+    auto decode = [&](int k) {
+        Tile T;
+        int t = tile0 + k * tstride;
+        T.n = t / tpi;
+        t -= T.n * tpi;
+        const int strip = t / p.g.tiles_per_strip;
+        const int mt = t - strip * p.g.tiles_per_strip;
+        T.x0 = strip * SW;
+        T.sw = min(SW, p.Wo - T.x0);
+        T.m0 = mt * TM;
+        T.y_first = T.m0 / SW;
+        int y_last = (T.m0 + TM - 1) / SW;
+        if (y_last > p.Ho - 1) y_last = p.Ho - 1;
+        T.iy0 = T.y_first * p.stride - p.pad;
+        T.ix0 = T.x0 * p.stride - p.pad;
+        T.npix = ((y_last - T.y_first) * p.stride + (KH - 1) * p.dil + 1) * CW;
+        return T;
+    };
+
+    // weights of stream stage `st` (chunk st/SPC of the channel loop, tap group st%SPC): WPS pieces per wave
+    auto issue_w = [&](int st) {
+        const int gc = st / SPC, tg = st - gc * SPC;
+        const int chunk = gc % nchunks;
+        const int dst = (st % NWB) * WBUF;
+#pragma unroll
+        for (int q = 0; q < WPS; ++q) {
+            const int i = q * NW + wave;
+            const int tap_l = i / WT, tl = i - tap_l * WT;
+            const int tap = tg * TPS + tap_l;
+            const int tile = p.tile_off + cob * WT + tl;
+            const bf16_t* base = tile < p.ntiles_w ? wp + ((long)(chunk * NTAP + tap) * p.ntiles_w + tile) * 512 : (const bf16_t*)p.zero_page;
+            dma16(base + lane * 8, (void*)(lds + dst + i * 1024));
+        }
+    };
+    // halo tile of stream chunk gc: exactly NA pieces per wave (padded with zero-page loads into the scratch slot).
+    // The per-lane element offset of each piece inside the current source tensor is computed once per (tile, source)
+    // (prep_a) -- per chunk only the channel offset is added.
+    int aoff[NA];          // element offset of (pixel, channel group) in the source, or -1 when outside the window
+    int a_src = -1;        // source the offsets were prepared for
+    int a_sC = 0;
+    const bf16_t* a_ptr = nullptr;
+    int a_npieces = 0;
+    auto prep_a = [&](const Tile& T, int si) {
+        a_ptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
+        const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
+        const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
+        a_sC = si == 0 ? p.src[0].C : (si == 1 ? p.src[1].C : p.src[2].C);
+        const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
+        const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
+        a_src = si;
+        a_npieces = (T.npix + 15) >> 4;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int j = q * NW + wave;
+            const int hp = j * 16 + (lane >> 2);
+            const int kg = (lane & 3) ^ ((hp >> 1) & 2);
+            const int rr = div_magic(hp, p.g.inv_CW);
+            const int cc = hp - rr * CW;
+            const int iy = T.iy0 + rr, ix = T.ix0 + cc;
+            const bool ok = (hp < T.npix) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
+            aoff[q] = ok ? (((T.n * sH + iy + soy) * sW + (ix + sox)) * a_sC + kg * 8) : -1;
+        }
+    };
+    auto issue_a = [&](int gc, const Tile& T, bool new_tile) {
+        int si = 0, cl = gc % nchunks;
+        if (cl >= p.nchunk[0]) {
+            cl -= p.nchunk[0];
+            si = 1;
+            if (cl >= p.nchunk[1]) {
+                cl -= p.nchunk[1];
+                si = 2;
+            }
+        }
+        if (new_tile || si != a_src) prep_a(T, si);
+        const int dst = a_base + (gc & 1) * ABUF;
+        const int c0 = cl * 32;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int j = q * NW + wave;
+            const int kg8 = ((lane & 3) ^ (((j * 16 + (lane >> 2)) >> 1) & 2)) * 8;
+            const bool ok = (aoff[q] >= 0) && (c0 + kg8 < a_sC);
+            const bf16_t* src = ok ? a_ptr + ((long)aoff[q] + c0) : (const bf16_t*)p.zero_page;
+            const int d = j < a_npieces ? dst + j * 1024 : dummy_base;
+            dma16(src, (void*)(lds + d));
+        }
+    };
+
+    // buffer descriptor over the whole output tensor: masked lanes use an out-of-range offset (store dropped)
+    const long out_bytes = (long)p.N * p.oH * p.oW * p.outC * 2;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)(unsigned)(out_bytes > 0xfffffff0L ? 0xfffffff0L : out_bytes), 0x00020000);
+    float bias_r[CT / 2][8];  // this lane's output channels never change: fetch the bias once
+#pragma unroll
+    for (int pp = 0; pp < CT / 2; ++pp) {
+        const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bias_r[pp][i] = (p.bias && co < p.Cout) ? p.bias[co + i] : 0.f;
+    }
+    // retire these ordinary loads NOW: hipcc would otherwise hang a vmcnt(0) on their first use inside the stage loop,
+    // which would drain the LDS-DMA ring every stage
+#pragma unroll
+    for (int pp = 0; pp < CT / 2; ++pp)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bias_r[pp][i]));
+    auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
+#pragma unroll
+        for (int pp = 0; pp < CT / 2; ++pp) {
+            const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
+            const bool cok = co < p.Cout;
+            const float(&bv)[8] = bias_r[pp];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int m = T.m0 + (wpx * PT + pt) * 16 + l15;
+                const int y = div_magic(m, p.g.inv_SW);
+                const int tx = m - y * SW;
+                const bool ok = cok && (y < p.Ho) && (tx < T.sw);
+                const long idx = ((long)(T.n * p.oH + y * p.ostride + ooffy) * p.oW + (T.x0 + tx) * p.ostride + ooffx) * p.outC + co;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[2 * pp][pt][i] + bv[i];
+                    v[4 + i] = acc[2 * pp + 1][pt][i] + bv[4 + i];
+                }
+                if (p.mask_src) {
+                    u32x4 mk = u32x4{0u, 0u, 0u, 0u};
+                    if (ok) mk = *(const u32x4*)(p.mask_src + idx);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!(bf_lo(mk[i]) > 0.f)) v[2 * i] = 0.f;
+                        if (!(bf_hi(mk[i]) > 0.f)) v[2 * i + 1] = 0.f;
+                    }
+                }
+                if (p.accumulate) {
+                    u32x4 o = u32x4{0u, 0u, 0u, 0u};
+                    if (ok) o = *(const u32x4*)(p.out + idx);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[2 * i] += bf_lo(o[i]);
+                        v[2 * i + 1] += bf_hi(o[i]);
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                }
+                u32x4 r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+                const unsigned voff = ok ? (unsigned)(idx * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voff, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: A(0), W(0), W(1)
+    Tile ptile = decode(0);     // tile whose halo is being prefetched
+    int pk = 0;                 // index of ptile in this workgroup's list
+    issue_a(0, ptile, true);
+    issue_w(0);
+    if (GC * SPC > 1) issue_w(1);
+    constexpr int NST = (CT / 2) * PT;  // epilogue buffer stores per wave per tile (always issued)
+
+    int gc = 0;  // stream chunk counter
+    for (int ck = 0; ck < my_tiles; ++ck) {
+        const Tile ctile = decode(ck);
+        // accumulators and fragment offsets live for exactly one tile: no loop-carried copies across the epilogue
+        f32x4 acc[CT][PT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int boff[PT][KW];  // byte offset (inside a halo slot) of this lane's 16-byte fragment piece, per pixel fragment and kx
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = ctile.m0 + (wpx * PT + pt) * 16 + l15;
+            const int y = div_magic(m, p.g.inv_SW);
+            const int tx = m - y * SW;
+            const bool valid = (y < p.Ho) && (tx < ctile.sw);
+            const int hp0 = valid ? ((y - ctile.y_first) * p.stride * CW + tx * p.stride) : 0;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int hp = hp0 + kx * p.dil;
+                boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
+            }
+        }
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            // every wave may rely on the constant per-stage counts only while the two chunks ahead exist
+            const bool steady = gc + 2 < GC;
+            // first chunk after an epilogue: its 16-byte stores sit in the VMEM queue behind the loads stage 0/1 wait for
+            const bool after_epi = (c == 0) && gc > 0;
+            auto stage = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int st = gc * SPC + j;
+                constexpr int ALLOWED = vm_allowed<SPC, WPS, NA>(j);
+                if (!steady) {
+                    RSU_WAIT_VMCNT(0);
+                } else if (after_epi && j < 2) {
+                    RSU_WAIT_VMCNT(ALLOWED + NST);
+                } else {
+                    RSU_WAIT_VMCNT(ALLOWED);
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
+                if (SPC == 1) {
+                    if (gc + 1 < GC) {
+                        const bool nt = (c + 1 == nchunks);
+                        if (nt) {
+                            ++pk;
+                            ptile = decode(pk);
+                        }
+                        issue_a(gc + 1, ptile, nt);
+                    }
+                    if (st + 2 < GC * SPC) issue_w(st + 2);
+                } else {
+                    if (st + 2 < GC * SPC) issue_w(st + 2);
+                    if (j == 0 && gc + 1 < GC) {
+                        const bool nt = (c + 1 == nchunks);
+                        if (nt) {
+                            ++pk;
+                            ptile = decode(pk);
+                        }
+                        issue_a(gc + 1, ptile, nt);
+                    }
+                }
+                // ---- compute stage st from weight slot st%NWB and halo slot gc&1
+                const int wb = (st % NWB) * WBUF;
+                const int ab = a_base + (gc & 1) * ABUF;
+                bf16x8 fa[2][CT], fb[2][PT];
+                auto load_tap = [&](int tl, bf16x8(&a)[CT], bf16x8(&b)[PT]) {
+                    const int tap = j * TPS + tl;
+                    const int ky = tap / KW, kx = tap - ky * KW;
+                    const int rowoff = ab + ((ky * CW * p.dil) << 6);  // wave-uniform
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        a[ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + wb + ((tl * WT + wco * CT + ct) * 64 + lane) * 16);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        b[pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][kx] + rowoff));
+                };
+                load_tap(0, fa[0], fb[0]);
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl) {
+                    if (tl + 1 < TPS) load_tap(tl + 1, fa[(tl + 1) & 1], fb[(tl + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tl & 1][ct], fb[tl & 1][pt], acc[ct][pt], 0, 0, 0);
+                }
+            };
+            stage(std::integral_constant<int, 0>{});
+            if constexpr (SPC > 1) stage(std::integral_constant<int, 1>{});
+            if constexpr (SPC > 2) stage(std::integral_constant<int, 2>{});
+            static_assert(SPC <= 3, "at most three tap groups per chunk");
+        }
+        epilogue(ctile, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int CFG> struct Fwd2Cfg;
+template <> struct Fwd2Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8, NA = 7; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8, NA = 10; };
+template <> struct Fwd2Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 4, NA = 5; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 4, NA = 7; };
+
+static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
+
+IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
+    switch (cfg) {
+#define CASE(C) \
+    case C: return IgFwdCfgInfo{Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::CT * 16, Fwd2Cfg<C>::WPX * Fwd2Cfg<C>::PT * 16, 256};
+        CASE(IGF2_CFG_128x256)
+        CASE(IGF2_CFG_64x512)
+        CASE(IGF2_CFG_128x128)
+        CASE(IGF2_CFG_64x256)
+#undef CASE
+    }
+    return IgFwdCfgInfo{0, 0, 0};
+}
+int igemm_fwd2_max_pieces(int cfg) {
+    switch (cfg) {
+        case IGF2_CFG_128x256: return Fwd2Cfg<IGF2_CFG_128x256>::NA * 4;
+        case IGF2_CFG_64x512: return Fwd2Cfg<IGF2_CFG_64x512>::NA * 4;
+        case IGF2_CFG_128x128: return Fwd2Cfg<IGF2_CFG_128x128>::NA * 4;
+        case IGF2_CFG_64x256: return Fwd2Cfg<IGF2_CFG_64x256>::NA * 4;
+    }
+    return 0;
+}
+size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max) {
+    const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
+    const int tps = tps2_for(ci.TN, ntap);
+    return (size_t)3 * tps * (ci.TN / 16) * 1024 + (size_t)2 * npix_max * 64 + 1024;
+}
+
+template <int CFG, int NTAP, int KW>
+static hipError_t launch2_one(const IgFwdParams& p, int gx, int gy, hipStream_t st) {
+    using C = Fwd2Cfg<CFG>;
+    constexpr int TN = C::WCO * C::CT * 16;
+    constexpr int TPS = tps2_for(TN, NTAP);
+    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::NA>;
+    const size_t lds = igemm_fwd2_lds_bytes(CFG, NTAP, p.g.npix_max);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+template <int CFG>
+static hipError_t launch2_cfg(int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
+    switch (ntap) {
+        case 9: return launch2_one<CFG, 9, 3>(p, gx, gy, st);
+        case 4: return launch2_one<CFG, 4, 2>(p, gx, gy, st);
+        case 1: return launch2_one<CFG, 1, 1>(p, gx, gy, st);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
+    switch (cfg) {
+        case IGF2_CFG_128x256: return launch2_cfg<IGF2_CFG_128x256>(ntap, p, gx, gy, st);
+        case IGF2_CFG_64x512: return launch2_cfg<IGF2_CFG_64x512>(ntap, p, gx, gy, st);
+        case IGF2_CFG_128x128: return launch2_cfg<IGF2_CFG_128x128>(ntap, p, gx, gy, st);
+        case IGF2_CFG_64x256: return launch2_cfg<IGF2_CFG_64x256>(ntap, p, gx, gy, st);
+    }
+    return hipErrorInvalidValue;
+}

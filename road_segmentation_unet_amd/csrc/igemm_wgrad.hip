@@ -16,7 +16,8 @@
 #include "igemm.h"
 
 template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK>
-__global__ void __launch_bounds__(WCF* WCS * 64) igemm_wgrad_kernel(const IgWgradParams p) {
+__global__ void __launch_bounds__(WCF* WCS * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+igemm_wgrad_kernel(const IgWgradParams p) {
     constexpr int NW = WCF * WCS;
     constexpr int CFB = WCF * CFT * 16;  // must be 64
     constexpr int CSB = WCS * CST * 16;  // 64 or 16
@@ -48,6 +49,20 @@ __global__ void __launch_bounds__(WCF* WCS * 64) igemm_wgrad_kernel(const IgWgra
         for (int a = 0; a < CFT; ++a)
 #pragma unroll
             for (int b = 0; b < CST; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane byte offsets of the transposed reads of the F tile (independent of the pixel tile): [k-step][read][cf tile]
+    int foff[TMK / 32][2][CFT];
+#pragma unroll
+    for (int ks = 0; ks < TMK / 32; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int ml = ks * 32 + rd * 16 + 4 * g4 + q4;
+#pragma unroll
+            for (int ct = 0; ct < CFT; ++ct) {
+                const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
+                foff[ks][rd][ct] = ml * 128 + ((((ch >> 4) ^ ((ml >> 1) & 3))) << 5) + (ch & 15) * 2;
+            }
+        }
 
     struct Tile { int n, x0, sw, m0, y_first, npix; };
     auto decode = [&](int tile) {
@@ -110,58 +125,80 @@ __global__ void __launch_bounds__(WCF* WCS * 64) igemm_wgrad_kernel(const IgWgra
             issue(nt, buf ^ 1);
         }
         const int fb = buf * FBUF, sb = s_base + buf * SBUF;
+        // per-lane byte offsets of the transposed reads of the S halo tile for this pixel tile: [k-step][read][kx][cs tile].
+        // CW is a multiple of 8 pixels, so a ky shift (whole halo rows) keeps the swizzle: it is added as a scalar.
+        int soff[TMK / 32][2][KW][CST];
 #pragma unroll
-        for (int ks = 0; ks < TMK / 32; ++ks) {
-            // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
-            bf16x8 fa[CFT];
-            int hps[2];
+        for (int ks = 0; ks < TMK / 32; ++ks)
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
-                const int ml = ks * 32 + rd * 16 + 4 * g4 + q4;
-                const int m = cur.m0 + ml;
+                const int m = cur.m0 + ks * 32 + rd * 16 + 4 * g4 + q4;
                 const int y = div_magic(m, p.g.inv_SW);
                 const int tx = m - y * SW;
                 const bool valid = (y < p.Hf) && (tx < cur.sw);
-                hps[rd] = valid ? ((y - cur.y_first) * p.stride * CW + tx * p.stride) : 0;
+                const int hp0 = valid ? ((y - cur.y_first) * p.stride * CW + tx * p.stride) : 0;
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int hp = hp0 + kx * p.dil;
+#pragma unroll
+                    for (int st = 0; st < CST; ++st) {
+                        const int ch = (wcs * CST + st) * 16 + 4 * p4;
+                        soff[ks][rd][kx][st] = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
+                                                          : (hp * SPITCH + ch * 2);
+                    }
+                }
+            }
+        // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
+        auto load_F = [&](int ks, bf16x8(&fa)[CFT]) {
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
 #pragma unroll
                 for (int ct = 0; ct < CFT; ++ct) {
-                    const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
-                    const int off = ml * 128 + ((((ch >> 4) ^ ((ml >> 1) & 3))) << 5) + (ch & 15) * 2;
                     const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(lds + fb + off));
+                        (__attribute__((address_space(3))) bf16x4*)(lds + (fb + foff[ks][rd][ct])));
                     fa[ct][rd * 4 + 0] = v[0];
                     fa[ct][rd * 4 + 1] = v[1];
                     fa[ct][rd * 4 + 2] = v[2];
                     fa[ct][rd * 4 + 3] = v[3];
                 }
             }
+        };
+        // B operand: S (cols = cs) shifted by the tap
+        auto load_S = [&](int ks, int tap, bf16x8(&sv)[CST]) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+            const int rowoff = sb + ky * CW * p.dil * SPITCH;  // wave-uniform
 #pragma unroll
-            for (int tap = 0; tap < NTAP; ++tap) {
-                const int ky = tap / KW, kx = tap - ky * KW;
-                const int toff = (ky * CW + kx) * p.dil;
-                bf16x8 sbv[CST];
+            for (int rd = 0; rd < 2; ++rd) {
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const int hp = hps[rd] + toff;
-#pragma unroll
-                    for (int st = 0; st < CST; ++st) {
-                        const int ch = (wcs * CST + st) * 16 + 4 * p4;
-                        const int off = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
-                                                   : (hp * SPITCH + ch * 2);
-                        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) bf16x4*)(lds + sb + off));
-                        sbv[st][rd * 4 + 0] = v[0];
-                        sbv[st][rd * 4 + 1] = v[1];
-                        sbv[st][rd * 4 + 2] = v[2];
-                        sbv[st][rd * 4 + 3] = v[3];
-                    }
+                for (int st = 0; st < CST; ++st) {
+                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4*)(lds + (rowoff + soff[ks][rd][kx][st])));
+                    sv[st][rd * 4 + 0] = v[0];
+                    sv[st][rd * 4 + 1] = v[1];
+                    sv[st][rd * 4 + 2] = v[2];
+                    sv[st][rd * 4 + 3] = v[3];
                 }
-#pragma unroll
-                for (int ct = 0; ct < CFT; ++ct)
-#pragma unroll
-                    for (int st = 0; st < CST; ++st)
-                        acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ct], sbv[st], acc[tap][ct][st], 0, 0, 0);
             }
+        };
+        // one software-pipelined sequence over (k-step, tap): operands of step+1 are requested before the MFMAs of step
+        constexpr int NS = (TMK / 32) * NTAP;
+        bf16x8 fa[2][CFT], sv[2][CST];
+        load_F(0, fa[0]);
+        load_S(0, 0, sv[0]);
+#pragma unroll
+        for (int step = 0; step < NS; ++step) {
+            const int ks = step / NTAP, tap = step % NTAP;
+            if (step + 1 < NS) {
+                const int ks1 = (step + 1) / NTAP, tap1 = (step + 1) % NTAP;
+                if (tap1 == 0) load_F(ks1, fa[ks1 & 1]);
+                load_S(ks1, tap1, sv[(step + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < CFT; ++ct)
+#pragma unroll
+                for (int st = 0; st < CST; ++st)
+                    acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
         }
         __syncthreads();
         cur = nt;

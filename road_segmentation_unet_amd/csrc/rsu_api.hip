@@ -198,12 +198,52 @@ static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int
     return have;
 }
 
+// second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
+struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x; };
+static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int force_cfg) {
+    double best_cost = 1e300;
+    bool have = false;
+    for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
+        if (force_cfg >= 0 && cfg != force_cfg) continue;
+        const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
+        if (Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
+        if (Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
+        const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
+        int cap = (int)((160 * 1024 - fixed) / 128);
+        const int cap2 = igemm_fwd2_max_pieces(cfg) * 16;
+        if (cap2 < cap) cap = cap2;
+        TileGeo g;
+        if (!plan_geo(g, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
+        const int ncob = cdiv(Cout, ci.TN);
+        const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
+        long workers = 256 / ncob;
+        if (workers < 1) workers = 1;
+        if (workers > ntile_m) workers = ntile_m;
+        const long rounds = (ntile_m + workers - 1) / workers;
+        // per tile: MFMA work ~ TM*TN per (chunk, tap) + a fixed epilogue/bubble term
+        const double cost = (double)rounds * ((double)ci.TM * ci.TN + 4096.0);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best.cfg = cfg;
+            best.g = g;
+            best.ncob = ncob;
+            best.grid_x = (int)(workers * ncob);
+            have = true;
+        }
+    }
+    return have;
+}
+
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
                    int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
     const int kh = ntap / kw;
+    const long out_bytes = (long)N * oH * oW * outC * 2;
+    const bool gen2 = env_int("RSU_FWD_GEN", 2) == 2 && out_bytes < 0xfffffff0L;
     FwdPlan pl;
-    if (!plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
+    Fwd2Plan pl2;
+    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD2_CFG", -1));
+    if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
     p.nsrc = nsrc;
@@ -232,6 +272,12 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.dil = dil; p.stride = stride; p.pad = pad;
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
+    if (use2) {
+        p.ncob = pl2.ncob;
+        p.g = pl2.g;
+        HIP_CHECK_RET(igemm_fwd2_launch(pl2.cfg, ntap, p, pl2.grid_x, gy, st));
+        return RSU_OK;
+    }
     p.ncob = pl.ncob;
     p.g = pl.g;
     const long gx = (long)N * pl.g.nstrips * pl.g.tiles_per_strip * pl.ncob;
