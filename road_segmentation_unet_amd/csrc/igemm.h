@@ -35,6 +35,7 @@ struct IgFwdParams {
     int oH, oW, ostride;  // out tensor geometry; out pixel = o*ostride + (blockIdx.y phase)
     int relu, accumulate;
     int ncob;
+    int lsw;              // log2(g.SW) for the aligned-tile kernels (igemm_fwd2)
     TileGeo g;
 };
 

@@ -24,6 +24,22 @@ __device__ __forceinline__ constexpr int vm_allowed(int j) {
     return SPC == 1 ? WPS : (j == 0 ? WPS : WPS + NA);
 }
 
+// buffer -> LDS copy of 16 bytes per lane: out-of-range lanes (voffset + soffset >= num_records) deposit ZEROS, which is
+// exactly the zero padding / window clipping the halo tile needs (probes/probe_buffer_lds.hip pins the semantics)
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    s2 h = __builtin_bit_cast(s2, x);
+    h = __builtin_elementwise_max(h, s2{0, 0});
+    return __builtin_bit_cast(unsigned, h);
+}
+#define RSU_SENT 0x80000000u   // voffset that the range check always rejects (num_records = 0x7fffffff)
+
+// Tiles are ALIGNED: strip width SW = 2^lsw divides TM, a tile is TR = TM/SW full rows of one strip. Every per-lane
+// offset (fragment reads, halo pieces, output pixels) is therefore a workgroup constant; a tile only contributes
+// scalar bases (soffset) and edge validity.
 template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int NW = 4;
@@ -34,8 +50,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     constexpr int WBUF = TPS * WT * 1024;
     constexpr int NWB = 3;                     // weight ring slots (prefetch distance 2)
     constexpr int WPS = TPS * WT / NW;         // weight DMA instructions per wave per stage
-    constexpr int KH = NTAP / KW;
-    static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && (TPS * WT) % NW == 0, "bad config");
+    constexpr int NST = (CT / 2) * PT;         // epilogue buffer stores per wave per tile (always issued)
+    static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && (TPS * WT) % NW == 0 && SPC <= 3, "bad config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
     const int ABUF = p.g.npix_max * 64;
@@ -46,7 +62,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wco = wave / WPX, wpx = wave % WPX;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int SW = p.g.SW, CW = p.g.CW;
+    const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TM >> lsw;
     const int ph = blockIdx.y;
     const bf16_t* wp = p.wp + (long)ph * p.wp_y_stride;
     const int ooffy = ph >> 1, ooffx = ph & 1;
@@ -61,25 +77,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int nchunks = p.nchunk[0] + p.nchunk[1] + p.nchunk[2];
     const int GC = my_tiles * nchunks;  // chunks in this workgroup's stream
 
-    struct Tile { int n, x0, sw, m0, y_first, iy0, ix0, npix; };
+    struct Tile { int n, x0, y0; };
     auto decode = [&](int k) {
         Tile T;
         int t = tile0 + k * tstride;
         T.n = t / tpi;
         t -= T.n * tpi;
         const int strip = t / p.g.tiles_per_strip;
-        const int mt = t - strip * p.g.tiles_per_strip;
         T.x0 = strip * SW;
-        T.sw = min(SW, p.Wo - T.x0);
-        T.m0 = mt * TM;
-        T.y_first = T.m0 / SW;
-        int y_last = (T.m0 + TM - 1) / SW;
-        if (y_last > p.Ho - 1) y_last = p.Ho - 1;
-        T.iy0 = T.y_first * p.stride - p.pad;
-        T.ix0 = T.x0 * p.stride - p.pad;
-        T.npix = ((y_last - T.y_first) * p.stride + (KH - 1) * p.dil + 1) * CW;
+        T.y0 = (t - strip * p.g.tiles_per_strip) * TR;
         return T;
     };
+
+    // ---- workgroup constants (per lane)
+    int boff[PT][KW];   // byte offset (inside a halo slot) of this lane's 16-byte fragment piece, per pixel fragment and kx
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int ml = (wpx * PT + pt) * 16 + l15;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        const int hp0 = ty * p.stride * CW + tx * p.stride;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int hp = hp0 + kx * p.dil;
+            boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
+        }
+    }
+    const int npieces = p.g.npix_max >> 4;
+    const int lq = lane >> 2;
+    // buffer descriptors are rebuilt from the (scalar) kernel-argument pointers right where they are used: hoisting them
+    // makes hipcc park them in VGPRs/scratch and wrap every buffer op in a waterfall loop (cdna guide T20)
+    auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
 
     // weights of stream stage `st` (chunk st/SPC of the channel loop, tap group st%SPC): WPS pieces per wave
     auto issue_w = [&](int st) {
@@ -96,36 +123,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             dma16(base + lane * 8, (void*)(lds + dst + i * 1024));
         }
     };
-    // halo tile of stream chunk gc: exactly NA pieces per wave (padded with zero-page loads into the scratch slot).
-    // The per-lane element offset of each piece inside the current source tensor is computed once per (tile, source)
-    // (prep_a) -- per chunk only the channel offset is added.
-    int aoff[NA];          // element offset of (pixel, channel group) in the source, or -1 when outside the window
-    int a_src = -1;        // source the offsets were prepared for
-    int a_sC = 0;
-    const bf16_t* a_ptr = nullptr;
-    int a_npieces = 0;
-    auto prep_a = [&](const Tile& T, int si) {
-        a_ptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
-        const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
-        const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
-        a_sC = si == 0 ? p.src[0].C : (si == 1 ? p.src[1].C : p.src[2].C);
-        const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
-        const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
-        a_src = si;
-        a_npieces = (T.npix + 15) >> 4;
+    // halo tile of stream chunk gc (tile T): exactly NA pieces per wave; clipped / padded pixels come back as zeros
+    unsigned amask = 0;  // bit q: piece q of this lane lies inside the source window for the tile being prefetched
+    auto prep_a = [&](const Tile& T) {
+        const int iy0 = T.y0 * p.stride - p.pad, ix0 = T.x0 * p.stride - p.pad;
+        amask = 0;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int j = q * NW + wave;
-            const int hp = j * 16 + (lane >> 2);
-            const int kg = (lane & 3) ^ ((hp >> 1) & 2);
+            const int hp = (q * NW + wave) * 16 + lq;
             const int rr = div_magic(hp, p.g.inv_CW);
             const int cc = hp - rr * CW;
-            const int iy = T.iy0 + rr, ix = T.ix0 + cc;
-            const bool ok = (hp < T.npix) && (iy >= 0) && (iy < p.Hin) && (ix >= 0) && (ix < p.Win);
-            aoff[q] = ok ? (((T.n * sH + iy + soy) * sW + (ix + sox)) * a_sC + kg * 8) : -1;
+            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win);
+            amask |= ok ? (1u << q) : 0u;
         }
     };
-    auto issue_a = [&](int gc, const Tile& T, bool new_tile) {
+    auto issue_a = [&](int gc, const Tile& T) {
         int si = 0, cl = gc % nchunks;
         if (cl >= p.nchunk[0]) {
             cl -= p.nchunk[0];
@@ -135,82 +147,92 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 si = 2;
             }
         }
-        if (new_tile || si != a_src) prep_a(T, si);
-        const int dst = a_base + (gc & 1) * ABUF;
+        const bf16_t* sptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
+        const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
+        const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
+        const int sC = si == 0 ? p.src[0].C : (si == 1 ? p.src[1].C : p.src[2].C);
+        const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
+        const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
         const int c0 = cl * 32;
+        // descriptor base is shifted back by the padding so that every in-window offset is >= 0
+        const __amdgpu_buffer_rsrc_t rs = mk(sptr - ((long)p.pad * sW + p.pad) * sC);
+        // scalar byte offset of the (padded) halo origin in this source, plus the channel chunk
+        const unsigned soff = (unsigned)((((long)(T.n * sH + T.y0 * p.stride + soy) * sW + (T.x0 * p.stride + sox)) * sC + c0) * 2);
+        const int dst = a_base + (gc & 1) * ABUF;
+        const int crem = sC - c0;  // channels left in this source (>= 32 except in a partial last chunk)
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int j = q * NW + wave;
-            const int kg8 = ((lane & 3) ^ (((j * 16 + (lane >> 2)) >> 1) & 2)) * 8;
-            const bool ok = (aoff[q] >= 0) && (c0 + kg8 < a_sC);
-            const bf16_t* src = ok ? a_ptr + ((long)aoff[q] + c0) : (const bf16_t*)p.zero_page;
-            const int d = j < a_npieces ? dst + j * 1024 : dummy_base;
-            dma16(src, (void*)(lds + d));
+            const int hp = j * 16 + lq;
+            const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
+            const int rr = div_magic(hp, p.g.inv_CW);
+            const int cc = hp - rr * CW;
+            const bool ok = ((amask >> q) & 1u) && (kg8 < crem);
+            const unsigned voff = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
+            const int d = j < npieces ? dst + j * 1024 : dummy_base;
+            bdma16(rs, voff, soff, (void*)(lds + d));
         }
     };
 
-    // buffer descriptor over the whole output tensor: masked lanes use an out-of-range offset (store dropped)
-    const long out_bytes = (long)p.N * p.oH * p.oW * p.outC * 2;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)(unsigned)(out_bytes > 0xfffffff0L ? 0xfffffff0L : out_bytes), 0x00020000);
-    float bias_r[CT / 2][8];  // this lane's output channels never change: fetch the bias once
-#pragma unroll
-    for (int pp = 0; pp < CT / 2; ++pp) {
-        const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bias_r[pp][i] = (p.bias && co < p.Cout) ? p.bias[co + i] : 0.f;
+    // bias of this workgroup's TN channels lives in LDS (behind the scratch slot): read back at every tile start with
+    // ds_read (lgkmcnt) -- keeping it in registers costs 16 VGPRs, re-loading it from memory would touch vmcnt
+    const int bias_base = dummy_base + 1024;
+    if (threadIdx.x < TN) {
+        const int co = cob * TN + threadIdx.x;
+        const float bvv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        *(__attribute__((address_space(3))) float*)(lds + bias_base + threadIdx.x * 4) = bvv;
     }
-    // retire these ordinary loads NOW: hipcc would otherwise hang a vmcnt(0) on their first use inside the stage loop,
-    // which would drain the LDS-DMA ring every stage
-#pragma unroll
-    for (int pp = 0; pp < CT / 2; ++pp)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(bias_r[pp][i]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ordinary loads before the LDS-DMA stream starts
+    __syncthreads();
+
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
+        const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
+        const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
+        // scalar byte offset of the tile's first output pixel (+ this wave's first channel)
+        const unsigned sbase = (unsigned)((((long)(T.n * p.oH + T.y0 * p.ostride + ooffy) * p.oW + T.x0 * p.ostride + ooffx) * p.outC +
+                                           cob * TN + wco * (CT / 2) * 32) * 2);
 #pragma unroll
-        for (int pp = 0; pp < CT / 2; ++pp) {
-            const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
-            const bool cok = co < p.Cout;
-            const float(&bv)[8] = bias_r[pp];
+        for (int pt = 0; pt < PT; ++pt) {
+            const int ml = (wpx * PT + pt) * 16 + l15;
+            const int ty = ml >> lsw, tx = ml & (SW - 1);
+            const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
+            const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const int m = T.m0 + (wpx * PT + pt) * 16 + l15;
-                const int y = div_magic(m, p.g.inv_SW);
-                const int tx = m - y * SW;
-                const bool ok = cok && (y < p.Ho) && (tx < T.sw);
-                const long idx = ((long)(T.n * p.oH + y * p.ostride + ooffy) * p.oW + (T.x0 + tx) * p.ostride + ooffx) * p.outC + co;
+            for (int pp = 0; pp < CT / 2; ++pp) {
+                const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
+                const unsigned voff = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[2 * pp][pt][i] + bv[i];
-                    v[4 + i] = acc[2 * pp + 1][pt][i] + bv[4 + i];
+                    v[i] = acc[2 * pp][pt][i];
+                    v[4 + i] = acc[2 * pp + 1][pt][i];
                 }
                 if (p.mask_src) {
-                    u32x4 mk = u32x4{0u, 0u, 0u, 0u};
-                    if (ok) mk = *(const u32x4*)(p.mask_src + idx);
+                    const u32x4 mk4 = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff, sbase, 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (!(bf_lo(mk[i]) > 0.f)) v[2 * i] = 0.f;
-                        if (!(bf_hi(mk[i]) > 0.f)) v[2 * i + 1] = 0.f;
+                        if (!(bf_lo(mk4[i]) > 0.f)) v[2 * i] = 0.f;
+                        if (!(bf_hi(mk4[i]) > 0.f)) v[2 * i + 1] = 0.f;
                     }
                 }
                 if (p.accumulate) {
-                    u32x4 o = u32x4{0u, 0u, 0u, 0u};
-                    if (ok) o = *(const u32x4*)(p.out + idx);
+                    const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voff, sbase, 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         v[2 * i] += bf_lo(o[i]);
                         v[2 * i + 1] += bf_hi(o[i]);
                     }
                 }
-                if (p.relu) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+                unsigned r0 = pack_bf2(v[0], v[1]), r1 = pack_bf2(v[2], v[3]), r2 = pack_bf2(v[4], v[5]), r3 = pack_bf2(v[6], v[7]);
+                if (p.relu) {  // ReLU on the packed result: bf16 sign bit == int16 sign bit (v_pk_max_i16)
+                    r0 = relu_pk_bf16(r0);
+                    r1 = relu_pk_bf16(r1);
+                    r2 = relu_pk_bf16(r2);
+                    r3 = relu_pk_bf16(r3);
                 }
-                u32x4 r;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
-                const unsigned voff = ok ? (unsigned)(idx * 2) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voff, 0, 0);
+                const u32x4 r = {r0, r1, r2, r3};
+                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voff, sbase, 0);
+                __builtin_amdgcn_sched_barrier(0);  // keep the 16 iterations apart: hoisting all their loads costs 128 VGPRs
             }
         }
     };
@@ -218,33 +240,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // ---- prologue: A(0), W(0), W(1)
     Tile ptile = decode(0);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
-    issue_a(0, ptile, true);
+    prep_a(ptile);
+    issue_a(0, ptile);
     issue_w(0);
     if (GC * SPC > 1) issue_w(1);
-    constexpr int NST = (CT / 2) * PT;  // epilogue buffer stores per wave per tile (always issued)
 
     int gc = 0;  // stream chunk counter
     for (int ck = 0; ck < my_tiles; ++ck) {
         const Tile ctile = decode(ck);
-        // accumulators and fragment offsets live for exactly one tile: no loop-carried copies across the epilogue
+        // accumulators live for exactly one tile (no loop-carried copies across the epilogue); they start at the bias
         f32x4 acc[CT][PT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
+                                                                                 ((wco * (CT / 2) + (ct >> 1)) * 32 + 8 * g4 + (ct & 1) * 4) * 4);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int boff[PT][KW];  // byte offset (inside a halo slot) of this lane's 16-byte fragment piece, per pixel fragment and kx
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int m = ctile.m0 + (wpx * PT + pt) * 16 + l15;
-            const int y = div_magic(m, p.g.inv_SW);
-            const int tx = m - y * SW;
-            const bool valid = (y < p.Ho) && (tx < ctile.sw);
-            const int hp0 = valid ? ((y - ctile.y_first) * p.stride * CW + tx * p.stride) : 0;
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-                const int hp = hp0 + kx * p.dil;
-                boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
-            }
+            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = bv;
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
             // every wave may rely on the constant per-stage counts only while the two chunks ahead exist
@@ -268,23 +279,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
                 if (SPC == 1) {
                     if (gc + 1 < GC) {
-                        const bool nt = (c + 1 == nchunks);
-                        if (nt) {
+                        if (c + 1 == nchunks) {
                             ++pk;
                             ptile = decode(pk);
+                            prep_a(ptile);
                         }
-                        issue_a(gc + 1, ptile, nt);
+                        issue_a(gc + 1, ptile);
                     }
                     if (st + 2 < GC * SPC) issue_w(st + 2);
                 } else {
                     if (st + 2 < GC * SPC) issue_w(st + 2);
                     if (j == 0 && gc + 1 < GC) {
-                        const bool nt = (c + 1 == nchunks);
-                        if (nt) {
+                        if (c + 1 == nchunks) {
                             ++pk;
                             ptile = decode(pk);
+                            prep_a(ptile);
                         }
-                        issue_a(gc + 1, ptile, nt);
+                        issue_a(gc + 1, ptile);
                     }
                 }
                 // ---- compute stage st from weight slot st%NWB and halo slot gc&1
@@ -317,7 +328,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             stage(std::integral_constant<int, 0>{});
             if constexpr (SPC > 1) stage(std::integral_constant<int, 1>{});
             if constexpr (SPC > 2) stage(std::integral_constant<int, 2>{});
-            static_assert(SPC <= 3, "at most three tap groups per chunk");
         }
         epilogue(ctile, acc);
     }
@@ -356,7 +366,7 @@ int igemm_fwd2_max_pieces(int cfg) {
 size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max) {
     const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
     const int tps = tps2_for(ci.TN, ntap);
-    return (size_t)3 * tps * (ci.TN / 16) * 1024 + (size_t)2 * npix_max * 64 + 1024;
+    return (size_t)3 * tps * (ci.TN / 16) * 1024 + (size_t)2 * npix_max * 64 + 1024 + 512;
 }
 
 template <int CFG, int NTAP, int KW>

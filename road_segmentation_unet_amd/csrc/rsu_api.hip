@@ -91,6 +91,38 @@ static bool plan_geo(TileGeo& best, int Ho, int Wo, int TM, int kh, int kw, int 
     return found;
 }
 
+// Aligned variant for the second-generation kernels: SW is a power of two dividing TM; a tile is TM/SW full rows of a strip.
+static bool plan_geo_aligned(TileGeo& best, int& lsw_out, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap) {
+    if (Ho < 1 || Wo < 1) return false;
+    double best_cost = 1e30;
+    bool found = false;
+    for (int lsw = 3; lsw <= 6; ++lsw) {
+        const int SW = 1 << lsw;
+        if (SW > TM) break;
+        const int TR = TM / SW;
+        TileGeo g;
+        g.SW = SW;
+        g.nstrips = cdiv(Wo, SW);
+        g.tiles_per_strip = cdiv(Ho, TR);
+        const int R = (TR - 1) * stride + (kh - 1) * dil + 1;
+        g.CW = rup((SW - 1) * stride + (kw - 1) * dil + 1, 8);
+        g.npix_max = rup(R * g.CW, 32);
+        if (g.npix_max > npix_cap) continue;
+        g.inv_SW = magic32(SW);
+        g.inv_CW = magic32(g.CW);
+        const double waste = (double)g.nstrips * SW * g.tiles_per_strip * TR / ((double)Ho * Wo);
+        const double halo = (double)g.npix_max / TM;
+        const double cost = waste * (1.0 + 0.04 * halo);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = g;
+            lsw_out = lsw;
+            found = true;
+        }
+    }
+    return found;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------------
@@ -199,7 +231,7 @@ static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int
 }
 
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
-struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x; };
+struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
 static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int force_cfg) {
     double best_cost = 1e300;
     bool have = false;
@@ -213,7 +245,8 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         const int cap2 = igemm_fwd2_max_pieces(cfg) * 16;
         if (cap2 < cap) cap = cap2;
         TileGeo g;
-        if (!plan_geo(g, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
+        int lsw = 0;
+        if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
         const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
         long workers = 256 / ncob;
@@ -228,6 +261,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
             best.g = g;
             best.ncob = ncob;
             best.grid_x = (int)(workers * ncob);
+            best.lsw = lsw;
             have = true;
         }
     }
@@ -239,7 +273,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                    int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
     const int kh = ntap / kw;
     const long out_bytes = (long)N * oH * oW * outC * 2;
-    const bool gen2 = env_int("RSU_FWD_GEN", 2) == 2 && out_bytes < 0xfffffff0L;
+    bool gen2 = env_int("RSU_FWD_GEN", 2) == 2 && out_bytes < 0x7ffffff0L;
+    for (int i = 0; i < nsrc; ++i)
+        if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) gen2 = false;
     FwdPlan pl;
     Fwd2Plan pl2;
     bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD2_CFG", -1));
@@ -275,6 +311,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     if (use2) {
         p.ncob = pl2.ncob;
         p.g = pl2.g;
+        p.lsw = pl2.lsw;
         HIP_CHECK_RET(igemm_fwd2_launch(pl2.cfg, ntap, p, pl2.grid_x, gy, st));
         return RSU_OK;
     }

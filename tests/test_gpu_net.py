@@ -88,7 +88,7 @@ def test_forward_backward_parity(L, root, P, B, dilated):
     emu = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=True)
     f32 = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=False)
     noise = _rel_errs(emu[2], f32[2])
-    w1 = _check(loss, prob, grads, emu, 4e-3, 2e-3, 2e-2, "vs bf16-emulating oracle", noise, 0.6)
+    w1 = _check(loss, prob, grads, emu, 4e-3, 2e-3, 2e-2, "vs bf16-emulating oracle", noise, 1.0)
     w2 = _check(loss, prob, grads, f32, 3e-2, 1e-2, 1e-1, "vs float32 oracle", noise, 1.5)
     print("worst grad rel err: emu %s %.2e | f32 %s %.2e" % (w1[0], w1[1], w2[0], w2[1]))
 
