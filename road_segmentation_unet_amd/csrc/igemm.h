@@ -67,6 +67,7 @@ struct IgWgradParams {
     const void* zero_page;
     int N, dil, stride;
     int nsplit, ntiles_total;
+    int lsw;            // log2(g.SW): tiles are aligned (SW divides the pixel tile)
     TileGeo g;          // TM of this geometry = pixels per reduction tile
 };
 enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_NCFG = 2 };

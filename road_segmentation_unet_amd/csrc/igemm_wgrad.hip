@@ -15,6 +15,13 @@
 // fp32 slab; reduce_slabs (elementwise.hip) sums the splits deterministically.
 #include "igemm.h"
 
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+#define RSU_SENT 0x80000000u   // voffset the range check always rejects (num_records = 0x7fffffff): the lane deposits zeros
+
+// Tiles are ALIGNED (strip width SW = 2^lsw divides TMK; a tile = TMK/SW full rows of one strip), so every per-lane LDS
+// read offset is a workgroup constant and a pixel tile only contributes scalar bases + edge validity.
 template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK>
 __global__ void __launch_bounds__(WCF* WCS * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 igemm_wgrad_kernel(const IgWgradParams p) {
@@ -37,7 +44,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     const int wcf = wave / WCS, wcs = wave % WCS;
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
     const int cfb = blockIdx.x, csb = blockIdx.y, z = blockIdx.z;
-    const int SW = p.g.SW, CW = p.g.CW;
+    const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TMK >> lsw;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     const int Hs = (p.Hf - 1) * p.stride + (KH - 1) * p.dil + 1;  // S window extent
     const int Ws = (p.Wf - 1) * p.stride + (KW - 1) * p.dil + 1;
@@ -50,8 +57,9 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
             for (int b = 0; b < CST; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane byte offsets of the transposed reads of the F tile (independent of the pixel tile): [k-step][read][cf tile]
-    int foff[TMK / 32][2][CFT];
+    // per-lane byte offsets of the transposed LDS reads (workgroup constants)
+    int foff[TMK / 32][2][CFT];       // F tile: [k-step][read][cf tile]
+    int soff[TMK / 32][2][KW][CST];   // S halo tile: [k-step][read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
 #pragma unroll
     for (int ks = 0; ks < TMK / 32; ++ks)
 #pragma unroll
@@ -62,53 +70,61 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                 const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
                 foff[ks][rd][ct] = ml * 128 + ((((ch >> 4) ^ ((ml >> 1) & 3))) << 5) + (ch & 15) * 2;
             }
+            const int ty = ml >> lsw, tx = ml & (SW - 1);
+            const int hp0 = ty * p.stride * CW + tx * p.stride;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int hp = hp0 + kx * p.dil;
+#pragma unroll
+                for (int st = 0; st < CST; ++st) {
+                    const int ch = (wcs * CST + st) * 16 + 4 * p4;
+                    soff[ks][rd][kx][st] = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
+                                                      : (hp * SPITCH + ch * 2);
+                }
+            }
         }
 
-    struct Tile { int n, x0, sw, m0, y_first, npix; };
+    struct Tile { int n, x0, y0; };
     auto decode = [&](int tile) {
         Tile T;
         T.n = tile / tpi;
         int r = tile - T.n * tpi;
         const int strip = r / p.g.tiles_per_strip;
-        const int mt = r - strip * p.g.tiles_per_strip;
         T.x0 = strip * SW;
-        T.sw = min(SW, p.Wf - T.x0);
-        T.m0 = mt * TMK;
-        T.y_first = T.m0 / SW;
-        int y_last = (T.m0 + TMK - 1) / SW;
-        if (y_last > p.Hf - 1) y_last = p.Hf - 1;
-        const int R = (y_last - T.y_first) * p.stride + (KH - 1) * p.dil + 1;
-        T.npix = R * CW;
+        T.y0 = (r - strip * p.g.tiles_per_strip) * TR;
         return T;
     };
+    auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
+    const int npieces_s = (p.g.npix_max + PPP - 1) / PPP;
     auto issue = [&](const Tile& T, int buf) {
-        // F tile: TMK pixels x 64 channels, 8 pixels per DMA piece
-        for (int j = wave; j < TMK / 8; j += NW) {
-            const int ml = j * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
-            const int m = T.m0 + ml;
-            const int y = div_magic(m, p.g.inv_SW);
-            const int tx = m - y * SW;
-            const int ch = cfb * 64 + c * 8;
-            const bool ok = (y < p.Hf) && (tx < T.sw) && (ch < p.Cf);
-            const bf16_t* src = ok ? p.F + ((long)(T.n * p.Hf + y) * p.Wf + T.x0 + tx) * p.Cf + ch : (const bf16_t*)p.zero_page;
-            dma16(src, (void*)(lds + buf * FBUF + j * 1024));
+        // F tile: TMK pixels x 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
+        {
+            const __amdgpu_buffer_rsrc_t rf = mk(p.F);
+            const unsigned soffF = (unsigned)((((long)(T.n * p.Hf + T.y0) * p.Wf + T.x0) * p.Cf + cfb * 64) * 2);
+            for (int j = wave; j < TMK / 8; j += NW) {
+                const int ml = j * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
+                const int ty = ml >> lsw, tx = ml & (SW - 1);
+                const bool ok = (T.y0 + ty < p.Hf) && (T.x0 + tx < p.Wf) && (cfb * 64 + c * 8 < p.Cf);
+                const unsigned voff = ok ? (unsigned)(((ty * p.Wf + tx) * p.Cf + c * 8) * 2) : RSU_SENT;
+                bdma16(rf, voff, soffF, (void*)(lds + buf * FBUF + j * 1024));
+            }
         }
         // S halo tile
-        const int npieces = (T.npix + PPP - 1) / PPP;
-        const int iy0 = T.y_first * p.stride, ix0 = T.x0 * p.stride;
-        for (int j = wave; j < npieces; j += NW) {
-            const int hp = j * PPP + lane / LPP;
-            const int pc = lane % LPP;
-            const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
-            const int rr = div_magic(hp, p.g.inv_CW);
-            const int cc = hp - rr * CW;
-            const int iy = iy0 + rr, ix = ix0 + cc;
-            const int ch = csb * CSB + c * 8;
-            const bool ok = (hp < T.npix) && (iy < Hs) && (ix < Ws) && (ch < p.S.C);
-            const bf16_t* src =
-                ok ? p.S.ptr + ((long)(T.n * p.S.H + iy + p.S.oy) * p.S.W + ix + p.S.ox) * p.S.C + ch : (const bf16_t*)p.zero_page;
-            dma16(src, (void*)(lds + s_base + buf * SBUF + j * 1024));
+        {
+            const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
+            const int iy0 = T.y0 * p.stride, ix0 = T.x0 * p.stride;
+            const unsigned soffS = (unsigned)((((long)(T.n * p.S.H + iy0 + p.S.oy) * p.S.W + ix0 + p.S.ox) * p.S.C + csb * CSB) * 2);
+            for (int j = wave; j < npieces_s; j += NW) {
+                const int hp = j * PPP + lane / LPP;
+                const int pc = lane % LPP;
+                const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
+                const int rr = div_magic(hp, p.g.inv_CW);
+                const int cc = hp - rr * CW;
+                const bool ok = (iy0 + rr < Hs) && (ix0 + cc < Ws) && (csb * CSB + c * 8 < p.S.C);
+                const unsigned voff = ok ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
+                bdma16(rs, voff, soffS, (void*)(lds + s_base + buf * SBUF + j * 1024));
+            }
         }
     };
 
@@ -119,35 +135,11 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     int buf = 0;
     for (; tile < p.ntiles_total; tile += p.nsplit) {
         const int nxt = tile + p.nsplit;
-        Tile nt = cur;
         if (nxt < p.ntiles_total) {
-            nt = decode(nxt);
+            const Tile nt = decode(nxt);
             issue(nt, buf ^ 1);
         }
         const int fb = buf * FBUF, sb = s_base + buf * SBUF;
-        // per-lane byte offsets of the transposed reads of the S halo tile for this pixel tile: [k-step][read][kx][cs tile].
-        // CW is a multiple of 8 pixels, so a ky shift (whole halo rows) keeps the swizzle: it is added as a scalar.
-        int soff[TMK / 32][2][KW][CST];
-#pragma unroll
-        for (int ks = 0; ks < TMK / 32; ++ks)
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int m = cur.m0 + ks * 32 + rd * 16 + 4 * g4 + q4;
-                const int y = div_magic(m, p.g.inv_SW);
-                const int tx = m - y * SW;
-                const bool valid = (y < p.Hf) && (tx < cur.sw);
-                const int hp0 = valid ? ((y - cur.y_first) * p.stride * CW + tx * p.stride) : 0;
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
-                    const int hp = hp0 + kx * p.dil;
-#pragma unroll
-                    for (int st = 0; st < CST; ++st) {
-                        const int ch = (wcs * CST + st) * 16 + 4 * p4;
-                        soff[ks][rd][kx][st] = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
-                                                          : (hp * SPITCH + ch * 2);
-                    }
-                }
-            }
         // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
         auto load_F = [&](int ks, bf16x8(&fa)[CFT]) {
 #pragma unroll
@@ -201,7 +193,6 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                     acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
         }
         __syncthreads();
-        cur = nt;
         buf ^= 1;
     }
 

@@ -371,14 +371,14 @@ static int wgrad_max_split(int Cf, int Cs, int csb) {
     int want = 512 / (cdiv(Cf, 64) * cdiv(Cs, csb));
     return want < 1 ? 1 : want;
 }
-struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles; };
+struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw; };
 static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
     pl.cfg = cfg;
     const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
     const int tmk = igemm_wgrad_tmk(cfg);
     const long fixed = 2L * tmk * 128;
     const int cap = (int)((160 * 1024 - fixed) / (2 * csb * 2));
-    if (!plan_geo(pl.g, Hf, Wf, tmk, kh, kw, dil, stride, cap)) return false;
+    if (!plan_geo_aligned(pl.g, pl.lsw, Hf, Wf, tmk, kh, kw, dil, stride, cap)) return false;
     pl.gx = cdiv(Cf, 64);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
@@ -405,6 +405,7 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.N = N; p.dil = dil; p.stride = stride;
     p.nsplit = pl.nsplit;
     p.ntiles_total = pl.ntiles;
+    p.lsw = pl.lsw;
     p.g = pl.g;
     HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
     HIP_CHECK_RET(ew_reduce_slabs(ws, out, pl.nsplit, ntap, CsOut, cs_off, S->C, CfOut, st));

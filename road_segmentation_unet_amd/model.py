@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference's model driver (/root/reference/src/tf_aerial_images.py:51-379):
+`Options` (the 30 flags) and `ConvolutionalModel` with train / predict / predict_batchwise / save / restore -- same names,
+argument meaning, batch/tiling conventions and quirks that matter for parity -- over the HIP path (unet.UNet).
+
+Data parallelism (new; the reference is single-device): when torch.distributed is initialised, `batch_size` is the GLOBAL
+minibatch, sharded contiguously over ranks; gradients are all-reduced (dist.GradBucketer); predict() shards tiles.
+"""
+import glob
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import images as dimages
+from .dist import GradBucketer, shard_indices
+from .unet import UNet, input_size_needed
+
+# (name, type, default, help) -- tf_aerial_images.py:15-46, same order
+FLAG_DEFS = [
+    ("batch_size", int, 25, "Batch size of training instances"),
+    ("dilated_layers", bool, False, "Add dilated CNN layers"),
+    ("dropout", float, 0.8, "Probability to keep an input"),
+    ("ensemble_prediction", bool, False, "Ensemble Prediction"),
+    ("eval_data_dir", str, None, "Directory containing eval images"),
+    ("eval_every", int, 500, "Number of steps between evaluations"),
+    ("eval_train", bool, False, "Evaluate training data"),
+    ("gpu", int, -1, "GPU to run the model on"),
+    ("image_augmentation", bool, False, "Augment training set of images with transformations"),
+    ("interactive", bool, False, "Spawn interactive Tensorflow session"),
+    ("logdir", str, os.path.abspath("./logdir"), "Directory where to write logfiles"),
+    ("lr", float, 0.01, "Initial learning rate"),
+    ("model_path", str, None, "Restore exact model path"),
+    ("momentum", float, 0.9, "Momentum"),
+    ("num_epoch", int, 5, "Number of pass on the dataset during training"),
+    ("num_eval_images", int, 4, "Number of images to predict for an evaluation"),
+    ("num_gpu", int, 1, "Number of available GPUs to run the model on"),
+    ("num_layers", int, 5, "Number of layers of the U-Net"),
+    ("patch_size", int, 128, "Size of the prediction image"),
+    ("pred_batch_size", int, 2, "Batch size of batchwise prediction"),
+    ("restore_date", str, None, "Restore the model from specific date"),
+    ("restore_epoch", int, None, "Restore the model from specific epoch"),
+    ("restore_model", bool, False, "Restore the model from previous checkpoint"),
+    ("root_size", int, 64, "Number of filters of the first U-Net layer"),
+    ("rotation_angles", str, None, "Rotation angles"),
+    ("save_path", str, os.path.abspath("./runs"), "Directory where to write checkpoints, overlays and submissions"),
+    ("seed", int, 2017, "Random seed for reproducibility"),
+    ("stride", int, 16, "Sliding delta for patches"),
+    ("train_data_dir", str, os.path.abspath("./data/training"), "Directory containing training images/ groundtruth/"),
+    ("train_score_every", int, 1000, "Compute training score after the given number of iterations"),
+]
+
+
+class Options(object):
+    """Options used by our model (tf_aerial_images.py:51-84). Construct with keyword overrides of the flag defaults;
+    `rotation_angles` accepts the flag string "a,b,c" and is stored as a list of ints like the reference."""
+
+    def __init__(self, **overrides):
+        for name, _typ, default, _help in FLAG_DEFS:
+            setattr(self, name, default)
+        for k, v in overrides.items():
+            if not hasattr(self, k):
+                raise AttributeError("unknown option %r" % k)
+            setattr(self, k, v)
+        ra = self.rotation_angles
+        if isinstance(ra, str):
+            self.rotation_angles = None if not ra else [int(i) for i in ra.split(",")]
+
+
+def pixel_f1(pred_masks, true_masks):
+    """F1 = 2 / (1/recall + 1/precision) (summary.py:141-147) at pixel level on binarised masks."""
+    p = np.asarray(pred_masks).reshape(-1) > 0.5
+    t = np.asarray(true_masks).reshape(-1) >= 0.5
+    tp = float(np.logical_and(p, t).sum())
+    if tp == 0:
+        return 0.0
+    recall, precision = tp / t.sum(), tp / p.sum()
+    return 2.0 / (1.0 / recall + 1.0 / precision)
+
+
+class ConvolutionalModel:
+    def __init__(self, options, session=None, device=None, params=None):
+        self._options = opts = options
+        self._session = session  # kept for signature parity; unused
+        np.random.seed(opts.seed)
+        self.input_size = input_size_needed(opts.patch_size, opts.num_layers)
+        self.experiment_name = datetime.now().strftime("%Y-%m-%dT%Hh%Mm%Ss")
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        assert opts.batch_size % self.world == 0, "global batch_size must divide evenly over ranks"
+        self.local_batch = opts.batch_size // self.world
+        if device is None:
+            device = "cuda:%d" % (opts.gpu if opts.gpu >= 0 else int(os.environ.get("LOCAL_RANK", "0")))
+        # the reference's graph is static in (batch, patch): one UNet serves training and (zero-padded) prediction batches
+        self.net = UNet(opts.num_layers, opts.root_size, opts.dilated_layers, self.local_batch, opts.patch_size, device=device,
+                        params=params, seed=opts.seed, training=True)
+        self._bucketer = None
+        if self.world > 1:
+            self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
+            self.net.on_grads = self._bucketer.ready
+            # identical initial weights on every rank (the reference has one copy; ranks must start from the same point)
+            dist.broadcast(self.net.flat_w, 0)
+            self.net.repack()
+
+    # ------------------------------------------------------------------ training
+    def train_step(self, patches, labels):
+        """One session.run([train, loss, predictions]) (tf_aerial_images.py:241-244) on this rank's shard.
+        patches [b,S,S,3] float, labels [b,P,P] in {0,1}; returns (global mean loss tensor, predictions [b,P,P] device tensor)."""
+        opts, net = self._options, self.net
+        if float(opts.dropout) != 1.0:
+            raise NotImplementedError("the HIP path implements dropout keep probability 1.0 only (pass --dropout=1.0, as the "
+                                      "reference's final model does, README.md:65)")
+        net.x.copy_(torch.as_tensor(patches).to(net.device, torch.float32))
+        net.labels.copy_(torch.as_tensor(labels).to(net.device, torch.int64))
+        net.forward_device()
+        if self._bucketer is not None:
+            self._bucketer.reset()
+        net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
+        loss = net.loss_sum / (opts.batch_size * opts.patch_size * opts.patch_size)
+        if self._bucketer is not None:
+            self._bucketer.finish()
+            dist.all_reduce(loss)
+        net.apply_momentum(opts.lr, opts.momentum)
+        return loss, net.prob
+
+    def train(self, patches, labels_patches, imgs, labels):
+        """Train the model for one epoch (tf_aerial_images.py:212-269): binarise labels at 0.5, shuffle with np.random,
+        `for offset in range(0, N - batch_size, batch_size)` (the final batch is dropped even when full)."""
+        opts = self._options
+        labels_patches = (np.asarray(labels_patches) >= 0.5) * 1.
+        num_train_patches = patches.shape[0]
+        indices = np.arange(0, num_train_patches)
+        np.random.shuffle(indices)
+        num_errors = torch.zeros((), dtype=torch.float64, device=self.net.device)
+        total = 0
+        last = None
+        for batch_i, offset in enumerate(range(0, num_train_patches - opts.batch_size, opts.batch_size)):
+            idx = shard_indices(indices, offset, opts.batch_size, self.rank, self.world)
+            loss, predictions = self.train_step(patches[idx], labels_patches[idx])
+            step = self.net.global_step
+            if self.rank == 0:
+                print("Batch {} Step {}".format(batch_i, step), end="\r")
+            num_errors += (self.net.labels.to(torch.float64) - predictions.to(torch.float64)).abs().sum()  # soft error (:249)
+            total += opts.batch_size
+            last = loss
+            if step > 0 and step % opts.eval_every == 0 and imgs is not None:
+                masks = self.predict(imgs[:opts.num_eval_images])
+                if self.rank == 0:
+                    print("\nstep {} loss {:.5f} pixel-F1 on {} eval images {:.4f}".format(
+                        step, float(loss), opts.num_eval_images, pixel_f1(masks, np.asarray(labels)[:opts.num_eval_images])))
+        self.last_epoch_stats = {"loss": None if last is None else float(last), "soft_errors": float(num_errors), "patches": total}
+        return self.last_epoch_stats
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def predict(self, imgs):
+        """Run inference on `imgs` and return predicted masks (tf_aerial_images.py:271-328).
+        imgs: [num_images, H, H, 3] in [0,1]; returns numpy [num_images, H, H, 1] road probabilities.
+        Ensemble x6 -> mirror border -> tiles (x-outer order) -> batched forward -> overlap average -> inverse ensemble.
+        Tiles are sharded contiguously over ranks; the accumulators are summed with one all-reduce."""
+        opts, net = self._options, self.net
+        dev = net.device
+        imgs_t = torch.as_tensor(np.asarray(imgs)).to(dev, torch.float32)
+        num_images = imgs_t.shape[0]
+        if opts.ensemble_prediction:
+            imgs_t = dimages.image_augmentation_ensemble(imgs_t).contiguous()
+            num_images = imgs_t.shape[0]
+        H, P, S, B = imgs_t.shape[1], opts.patch_size, self.input_size, self.local_batch
+        assert (H - P) % opts.stride == 0, "Stride sliding should cover the whole image"
+        pps = (H - P) // opts.stride + 1
+        num_patches = num_images * pps * pps
+        per = -(-num_patches // self.world)
+        lo, hi = min(self.rank * per, num_patches), min((self.rank + 1) * per, num_patches)
+        acc = dimages.OverlapAccumulator(num_images, H, P, opts.stride, device=dev)
+        was_training = net.training
+        net.training = False
+        for t0 in range(lo, hi, B):
+            nb = min(B, hi - t0)
+            if nb < B:
+                net.x.zero_()  # the reference pads the last batch with zero patches (tf_aerial_images.py:298-301)
+            dimages.extract_mirrored_patches(imgs_t, S, P, opts.stride, t0=t0, ntiles=nb, out=net.x[:nb])
+            net.forward_device()
+            acc.add(net.prob[:nb], t0)
+        net.training = was_training
+        if self.world > 1:
+            dist.all_reduce(acc.acc)
+            dist.all_reduce(acc.hits)
+        masks = acc.finish()
+        if opts.ensemble_prediction:
+            masks = dimages.invert_image_augmentation_ensemble(masks)
+        return masks.cpu().numpy()
+
+    def predict_batchwise(self, imgs, pred_batch_size):
+        """tf_aerial_images.py:330-341"""
+        masks = []
+        for i in range(int(np.ceil(imgs.shape[0] / pred_batch_size))):
+            start = i * pred_batch_size
+            masks.append(self.predict(imgs[start:start + pred_batch_size]))
+        return np.concatenate(masks, axis=0) if len(masks) > 1 else masks[0]
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, epoch=0):
+        """tf_aerial_images.py:343-349: {save_path}/{experiment_name}/model-epoch-{epoch:03d}.chkpt(.npz) holding every variable
+        under its TF name and layout, its Momentum slot and global_step."""
+        opts = self._options
+        path = os.path.abspath(os.path.join(opts.save_path, self.experiment_name, 'model-epoch-{:03d}.chkpt'.format(epoch)))
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in self.net.state_dict().items()})
+            print("Model saved in file: {}".format(path))
+        return path
+
+    def restore(self, date=None, epoch=None, file=None):
+        """Restores model from saved checkpoint (tf_aerial_images.py:351-379): explicit file, else newest experiment
+        directory under save_path (or `date`), newest epoch (or `epoch`)."""
+        opts = self._options
+        if file is not None:
+            model_data_dir = file
+        else:
+            if date is None:
+                dates = [d for d in glob.glob(os.path.join(opts.save_path, "*")) if os.path.isdir(d)]
+                model_data_dir = sorted(dates)[-1]
+            else:
+                model_data_dir = os.path.abspath(os.path.join(opts.save_path, date))
+            if epoch is None:
+                model_data_dir = sorted(glob.glob(os.path.abspath(os.path.join(model_data_dir, 'model-epoch-*.chkpt.npz'))))[-1][:-4]
+            else:
+                model_data_dir = os.path.abspath(os.path.join(model_data_dir, 'model-epoch-{:03d}.chkpt'.format(epoch)))
+        path = model_data_dir if model_data_dir.endswith(".npz") else model_data_dir + ".npz"
+        with np.load(path) as z:
+            self.net.load_state_dict({k.replace("|", "/"): z[k] for k in z.files})
+        print("Model restored from from file: {}".format(model_data_dir))

@@ -99,5 +99,41 @@ for r in rows1:
     lab[int(a) // 16, int(b) // 16] = int(v)
 out["g9_labels_img1"] = lab
 
+# G7 expand_and_rotate (a newer scipy here; the reference pinned scipy 1.0.0 -- order=0 resampling may differ at exact ties)
+import scipy  # noqa: E402
+g7 = rng.rand(2, 40, 40, 3).astype(np.float32)
+out["g7_in"] = g7
+out["g7_out_off6"] = images.expand_and_rotate(g7, [0, 15, 45], 6)
+g7m = rng.rand(2, 40, 40).astype(np.float32)
+out["g7_in3"], out["g7_out3_off0"] = g7m, images.expand_and_rotate(g7m, [0, 30], 0)
+out["g7_scipy"] = np.array(scipy.__version__)
+
+# F: the 30 command-line flags (name, type, default) parsed from the reference's DEFINE_* calls -- data, not source
+import json  # noqa: E402
+import re  # noqa: E402
+flags = []
+srcdir = os.path.join(REF, "src")
+os.chdir(srcdir)
+class _F:  # minimal recorder standing in for tf.app.flags
+    def __getattr__(self, name):
+        if name.startswith("DEFINE_"):
+            kind = name[len("DEFINE_"):]
+            return lambda n, d, h: flags.append([n, kind, d])
+        raise AttributeError(name)
+tfm = sys.modules["tensorflow"]
+tfm.app = types.SimpleNamespace(flags=_F(), run=lambda: None)
+tfm.app.flags.FLAGS = types.SimpleNamespace()
+sys.modules["summary"] = types.ModuleType("summary"); sys.modules["summary"].Summary = object
+try:
+    import tf_aerial_images  # noqa: E402,F401  (module-level DEFINE_* calls run against the recorder)
+except Exception as ex:  # anything after the flag definitions is irrelevant here
+    print("note: import stopped after flags:", type(ex).__name__)
+here = os.path.abspath("/root/reference")
+for f in flags:
+    if isinstance(f[2], str) and f[2].startswith(here):
+        f[2] = "<abs>" + f[2][len(here):]
+out["flags_json"] = np.array(json.dumps(flags))
+print("flags recorded:", len(flags))
+
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tiler_golden.npz"), **out)
 print("wrote", len(out), "arrays")

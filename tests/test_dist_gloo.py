@@ -1,0 +1,90 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: shard partitioning, the tail-first bucketed all-reduce and
+the DP-equivalence of the gradient definition (sum over ranks of per-rank gradients scaled by 1/GLOBAL pixel count ==
+gradient of the reference's reduce_mean over the whole batch, tf_aerial_images.py:108), using the CPU oracle as the model."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from road_segmentation_unet_amd.dist import GradBucketer, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ---- bucketed all-reduce, produced tail-first
+        n_live, n_flat = 5000, 5600
+        flat = torch.arange(n_flat, dtype=torch.float32) * (rank + 1)
+        b = GradBucketer(flat, n_live, min_bucket_elems=700)
+        for lo in (4800, 4500, 3000, 2990, 1200, 100):   # decreasing "everything >= lo is final"
+            b.ready(lo)
+        b.finish()
+        expect = torch.arange(n_flat, dtype=torch.float32) * sum(range(1, world + 1))
+        ok1 = bool(torch.equal(flat[:n_live], expect[:n_live]))
+        ok2 = bool(torch.equal(flat[n_live:], torch.arange(n_live, n_flat, dtype=torch.float32) * (rank + 1)))  # dead tail untouched
+        # second step re-uses the bucketer
+        flat.fill_(float(rank + 1))
+        b.reset(); b.ready(2500); b.finish()
+        ok3 = bool((flat[:n_live] == sum(range(1, world + 1))).all())
+
+        # ---- DP equivalence with the oracle as the model
+        from oracle import unet_oracle as U
+        L, root, P, B = 2, 8, 12, 4
+        S = U.input_size_needed(P, L)
+        rng = np.random.RandomState(5)
+        X = rng.rand(B, S, S, 3).astype(np.float32)
+        labels = (rng.rand(B, P, P) < 0.3).astype(np.int64)
+        params = U.init_params(L, root, False, seed=6, bias_scale=0.05)
+        idx = np.arange(B)
+        mine = shard_indices(idx, 0, B, rank, world)
+        _, _, g = U.loss_and_grads(params, X[mine], labels[mine], L, root, False)
+        scale = len(mine) / B   # oracle normalises by the LOCAL pixel count; the HIP head uses 1/global directly
+        flatg = torch.cat([torch.from_numpy(g[k].ravel() * scale) for k in sorted(g)])
+        gb = GradBucketer(flatg, flatg.numel(), min_bucket_elems=64)
+        gb.ready(flatg.numel() // 2); gb.finish()
+        _, _, gfull = U.loss_and_grads(params, X, labels, L, root, False)
+        ref = torch.cat([torch.from_numpy(gfull[k].ravel()) for k in sorted(gfull)])
+        err = float((flatg - ref).abs().max() / ref.abs().max())
+        q.put((rank, ok1, ok2, ok3, err, list(map(int, mine))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_allreduce_and_dp_equivalence():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = {}
+    for rank, ok1, ok2, ok3, err, mine in res:
+        assert ok1 and ok2 and ok3, (rank, ok1, ok2, ok3)
+        assert err < 1e-5, err
+        shards[rank] = mine
+    assert shards[0] == [0, 1] and shards[1] == [2, 3]
+
+
+def test_shard_indices_partitions_every_step():
+    idx = np.random.RandomState(0).permutation(103)
+    for world in (1, 2, 4, 8):
+        gb = 8
+        for off in range(0, 103 - gb, gb):
+            got = np.concatenate([shard_indices(idx, off, gb, r, world) for r in range(world)])
+            np.testing.assert_array_equal(got, idx[off:off + gb])

@@ -1,0 +1,70 @@
+"""CPU-side checks of the host mirrors of the reference interface: the 30 flags (names, types, defaults recorded from
+the reference's own DEFINE_* calls), Options, and the off-path host data functions against the reference-generated goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from road_segmentation_unet_amd import hostio
+from road_segmentation_unet_amd.cli import parse_options
+from road_segmentation_unet_amd.model import FLAG_DEFS, Options, pixel_f1
+
+
+def test_flags_match_reference(golden):
+    ref = json.loads(str(golden["flags_json"]))
+    assert len(ref) == 30 == len(FLAG_DEFS)
+    kinds = {"integer": int, "boolean": bool, "float": float, "string": str}
+    for (name, typ, default, _), (rname, rkind, rdefault) in zip(FLAG_DEFS, ref):
+        assert name == rname
+        assert typ is kinds[rkind], name
+        if isinstance(rdefault, str) and rdefault.startswith("<abs>"):
+            assert os.path.isabs(default) and default.endswith(os.path.basename(rdefault)), name  # os.path.abspath("./...")
+        else:
+            assert default == rdefault, name
+
+
+def test_options_and_cli_parsing():
+    o = Options()
+    assert (o.batch_size, o.dropout, o.lr, o.momentum, o.num_layers, o.patch_size, o.root_size, o.stride, o.seed) == \
+           (25, 0.8, 0.01, 0.9, 5, 128, 64, 16, 2017)
+    assert o.rotation_angles is None and o.dilated_layers is False
+    o = parse_options(["--num_layers=6", "--root_size", "64", "--patch_size=388", "--dilated_layers", "--rotation_angles=15,30,45",
+                       "--noensemble_prediction", "--restore_model=true", "--dropout=1.0"])
+    assert o.num_layers == 6 and o.patch_size == 388 and o.dilated_layers is True and o.rotation_angles == [15, 30, 45]
+    assert o.ensemble_prediction is False and o.restore_model is True and o.dropout == 1.0
+    with pytest.raises(AttributeError):
+        Options(no_such_flag=1)
+
+
+def test_hostio_against_reference_goldens(golden):
+    np.testing.assert_array_equal(hostio.mirror_border(golden["g1_in4"], 3), golden["g1_out4_n3"])
+    np.testing.assert_array_equal(hostio.extract_patches(golden["g2_in4"], 12, stride=4, predict_patch_size=4), golden["g2_out4_p12_s4_pp4"])
+    np.testing.assert_array_equal(hostio.extract_patches(golden["g2_in3"], 6, stride=3), golden["g2_out3_p6_s3"])
+    np.testing.assert_array_equal(hostio.quantize_mask(golden["g5_mask_in"], 0.25, 16), golden["g5_quant"])
+    np.testing.assert_array_equal(hostio.labels_for_patches(golden["g5_lab_in"]), golden["g5_lab_out"])
+    assert hostio.submission_rows(golden["g5_quant2"], 16) == str(golden["g5_csv"]).splitlines()[1:]
+    lab = golden["g9_labels_img1"]
+    mask = np.kron(lab.T, np.ones((16, 16)))[None, :, :, None]
+    assert hostio.submission_rows(mask, 16) == str(golden["g9_rows_img1"]).splitlines()
+
+
+def test_expand_and_rotate_golden(golden):
+    """generated with the scipy of this image (the reference pinned scipy 1.0.0): same library on both sides here"""
+    np.testing.assert_array_equal(hostio.expand_and_rotate(golden["g7_in"], [0, 15, 45], 6), golden["g7_out_off6"])
+    np.testing.assert_array_equal(hostio.expand_and_rotate(golden["g7_in3"], [0, 30], 0), golden["g7_out3_off0"])
+    with pytest.raises(TypeError):
+        hostio.expand_and_rotate(golden["g7_in3"], None, 0)  # the reference also fails when --rotation_angles is not given
+
+
+def test_csv_writer(tmp_path, golden):
+    fn = hostio.save_submission_csv(golden["g5_quant2"], str(tmp_path), 16)
+    assert open(fn).read() == str(golden["g5_csv"])
+
+
+def test_pixel_f1():
+    t = np.zeros((1, 4, 4)); t[0, :2] = 1
+    p = np.zeros((1, 4, 4)); p[0, :2, :2] = 0.9; p[0, 3, 3] = 0.8
+    # tp=4, fp=1, fn=4 -> precision 0.8, recall 0.5
+    assert abs(pixel_f1(p, t) - 2 / (1 / 0.5 + 1 / 0.8)) < 1e-12
+    assert pixel_f1(np.zeros_like(t), t) == 0.0
