@@ -40,18 +40,21 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
 // Tiles are ALIGNED: strip width SW = 2^lsw divides TM, a tile is TR = TM/SW full rows of one strip. Every per-lane
 // offset (fragment reads, halo pieces, output pixels) is therefore a workgroup constant; a tile only contributes
 // scalar bases (soffset) and edge validity.
+// NW = WCO*WPX waves: 4 (one per SIMD, big wave tiles) or 8 (two per SIMD: one wave's address arithmetic, waits and
+// LDS latency overlap its partner's MFMAs)
 template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) igemm_fwd2_kernel(const IgFwdParams p) {
-    constexpr int NW = 4;
-    static_assert(WCO * WPX == NW, "four waves");
+__global__ void __launch_bounds__(WCO* WPX * 64) __attribute__((amdgpu_waves_per_eu(WCO* WPX / 4, WCO* WPX / 4)))
+igemm_fwd2_kernel(const IgFwdParams p) {
+    constexpr int NW = WCO * WPX;
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
     constexpr int WT = TN / 16;
     constexpr int SPC = NTAP / TPS;
     constexpr int WBUF = TPS * WT * 1024;
     constexpr int NWB = 3;                     // weight ring slots (prefetch distance 2)
-    constexpr int WPS = TPS * WT / NW;         // weight DMA instructions per wave per stage
+    constexpr int WPS = (TPS * WT + NW - 1) / NW;  // weight DMA instructions per wave per stage (padded to a constant)
     constexpr int NST = (CT / 2) * PT;         // epilogue buffer stores per wave per tile (always issued)
-    static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && (TPS * WT) % NW == 0 && SPC <= 3, "bad config");
+    static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && SPC <= 3, "bad config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
     const int ABUF = p.g.npix_max * 64;
@@ -108,19 +111,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // makes hipcc park them in VGPRs/scratch and wrap every buffer op in a waterfall loop (cdna guide T20)
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
 
-    // weights of stream stage `st` (chunk st/SPC of the channel loop, tap group st%SPC): WPS pieces per wave
-    auto issue_w = [&](int st) {
-        const int gc = st / SPC, tg = st - gc * SPC;
-        const int chunk = gc % nchunks;
-        const int dst = (st % NWB) * WBUF;
+    // ---- weight prefetch stream. Stage s of a tile reads the contiguous block [s*TPS .. s*TPS+TPS) x [all tiles] of the
+    // packed weights, so the source is one scalar pointer that advances by a constant per stage and rewinds per tile;
+    // the pieces a wave copies have per-wave constant offsets. No divisions, ~5 scalar ops per piece.
+    const int nstage_tile = nchunks * SPC;
+    const long stage_bytes = (long)TPS * p.ntiles_w * 1024;
+    const char* const w_tile_base = (const char*)wp + (long)(p.tile_off + cob * WT) * 1024;
+    const char* w_cur = w_tile_base;   // source of the next stage to prefetch
+    int w_sit = 0;                     // its stage index inside the tile
+    int w_slot = 0;                    // its ring slot
+    int wpo[WPS];                      // byte offset of piece q inside a stage block, or -1 (padding piece / beyond the packed rows)
+#pragma unroll
+    for (int q = 0; q < WPS; ++q) {
+        const int i = q * NW + wave;
+        const int tap_l = i / WT, tl = i - tap_l * WT;
+        const bool real = (i < TPS * WT) && (p.tile_off + cob * WT + tl < p.ntiles_w);
+        wpo[q] = real ? (tap_l * p.ntiles_w + tl) * 1024 : -1;
+    }
+    auto issue_w = [&]() {
+        const int dst = w_slot * WBUF;
 #pragma unroll
         for (int q = 0; q < WPS; ++q) {
             const int i = q * NW + wave;
-            const int tap_l = i / WT, tl = i - tap_l * WT;
-            const int tap = tg * TPS + tap_l;
-            const int tile = p.tile_off + cob * WT + tl;
-            const bf16_t* base = tile < p.ntiles_w ? wp + ((long)(chunk * NTAP + tap) * p.ntiles_w + tile) * 512 : (const bf16_t*)p.zero_page;
-            dma16(base + lane * 8, (void*)(lds + dst + i * 1024));
+            const char* base = wpo[q] >= 0 ? w_cur + wpo[q] : (const char*)p.zero_page;
+            dma16(base + lane * 16, (void*)(lds + (i < TPS * WT ? dst + i * 1024 : dummy_base)));
+        }
+        w_slot = w_slot == NWB - 1 ? 0 : w_slot + 1;
+        if (++w_sit == nstage_tile) {
+            w_sit = 0;
+            w_cur = w_tile_base;
+        } else {
+            w_cur += stage_bytes;
         }
     };
     // halo tile of stream chunk gc (tile T): exactly NA pieces per wave; clipped / padded pixels come back as zeros
@@ -137,8 +158,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             amask |= ok ? (1u << q) : 0u;
         }
     };
+    int a_cl = 0;  // chunk (inside its tile) of the next halo to prefetch
     auto issue_a = [&](int gc, const Tile& T) {
-        int si = 0, cl = gc % nchunks;
+        int si = 0, cl = a_cl;
+        a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
         if (cl >= p.nchunk[0]) {
             cl -= p.nchunk[0];
             si = 1;
@@ -242,10 +265,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     int pk = 0;                 // index of ptile in this workgroup's list
     prep_a(ptile);
     issue_a(0, ptile);
-    issue_w(0);
-    if (GC * SPC > 1) issue_w(1);
+    issue_w();
+    if (GC * SPC > 1) issue_w();
 
-    int gc = 0;  // stream chunk counter
+    int gc = 0;      // stream chunk counter
+    int c_slot = 0;  // weight ring slot of the stage being computed
     for (int ck = 0; ck < my_tiles; ++ck) {
         const Tile ctile = decode(ck);
         // accumulators live for exactly one tile (no loop-carried copies across the epilogue); they start at the bias
@@ -276,30 +300,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
-                if (SPC == 1) {
-                    if (gc + 1 < GC) {
-                        if (c + 1 == nchunks) {
-                            ++pk;
-                            ptile = decode(pk);
-                            prep_a(ptile);
-                        }
-                        issue_a(gc + 1, ptile);
-                    }
-                    if (st + 2 < GC * SPC) issue_w(st + 2);
-                } else {
-                    if (st + 2 < GC * SPC) issue_w(st + 2);
-                    if (j == 0 && gc + 1 < GC) {
-                        if (c + 1 == nchunks) {
-                            ++pk;
-                            ptile = decode(pk);
-                            prep_a(ptile);
-                        }
-                        issue_a(gc + 1, ptile);
-                    }
-                }
                 // ---- compute stage st from weight slot st%NWB and halo slot gc&1
-                const int wb = (st % NWB) * WBUF;
+                const int wb = c_slot * WBUF;
                 const int ab = a_base + (gc & 1) * ABUF;
                 bf16x8 fa[2][CT], fb[2][PT];
                 auto load_tap = [&](int tl, bf16x8(&a)[CT], bf16x8(&b)[PT]) {
@@ -314,6 +316,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                         b[pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][kx] + rowoff));
                 };
                 load_tap(0, fa[0], fb[0]);
+                __builtin_amdgcn_sched_barrier(0);  // request the first fragments BEFORE the prefetch bookkeeping below
+                // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
+                if (SPC == 1) {
+                    if (gc + 1 < GC) {
+                        if (c + 1 == nchunks) {
+                            ++pk;
+                            ptile = decode(pk);
+                            prep_a(ptile);
+                        }
+                        issue_a(gc + 1, ptile);
+                    }
+                    if (st + 2 < GC * SPC) issue_w();
+                } else {
+                    if (st + 2 < GC * SPC) issue_w();
+                    if (j == 0 && gc + 1 < GC) {
+                        if (c + 1 == nchunks) {
+                            ++pk;
+                            ptile = decode(pk);
+                            prep_a(ptile);
+                        }
+                        issue_a(gc + 1, ptile);
+                    }
+                }
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     if (tl + 1 < TPS) load_tap(tl + 1, fa[(tl + 1) & 1], fb[(tl + 1) & 1]);
@@ -326,8 +351,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             };
             stage(std::integral_constant<int, 0>{});
-            if constexpr (SPC > 1) stage(std::integral_constant<int, 1>{});
-            if constexpr (SPC > 2) stage(std::integral_constant<int, 2>{});
+            c_slot = c_slot == NWB - 1 ? 0 : c_slot + 1;
+            if constexpr (SPC > 1) {
+                stage(std::integral_constant<int, 1>{});
+                c_slot = c_slot == NWB - 1 ? 0 : c_slot + 1;
+            }
+            if constexpr (SPC > 2) {
+                stage(std::integral_constant<int, 2>{});
+                c_slot = c_slot == NWB - 1 ? 0 : c_slot + 1;
+            }
         }
         epilogue(ctile, acc);
     }
@@ -335,31 +367,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
 // ---------------------------------------------------------------------------------------------
 template <int CFG> struct Fwd2Cfg;
-template <> struct Fwd2Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8, NA = 7; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8, NA = 10; };
-template <> struct Fwd2Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 4, NA = 5; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 4, NA = 7; };
+// NA = halo DMA pieces per wave per chunk (NA * NW * 16 pixels of halo at most)
+template <> struct Fwd2Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 4; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 5; };
+template <> struct Fwd2Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 3; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 4; };
+template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8, NA = 7; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8, NA = 10; };
 
 static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
 
 IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
     switch (cfg) {
 #define CASE(C) \
-    case C: return IgFwdCfgInfo{Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::CT * 16, Fwd2Cfg<C>::WPX * Fwd2Cfg<C>::PT * 16, 256};
+    case C: return IgFwdCfgInfo{Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::CT * 16, Fwd2Cfg<C>::WPX * Fwd2Cfg<C>::PT * 16, Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::WPX * 64};
         CASE(IGF2_CFG_128x256)
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
         CASE(IGF2_CFG_64x256)
+        CASE(IGF2_CFG_128x256_W4)
+        CASE(IGF2_CFG_64x512_W4)
 #undef CASE
     }
     return IgFwdCfgInfo{0, 0, 0};
 }
 int igemm_fwd2_max_pieces(int cfg) {
     switch (cfg) {
-        case IGF2_CFG_128x256: return Fwd2Cfg<IGF2_CFG_128x256>::NA * 4;
-        case IGF2_CFG_64x512: return Fwd2Cfg<IGF2_CFG_64x512>::NA * 4;
-        case IGF2_CFG_128x128: return Fwd2Cfg<IGF2_CFG_128x128>::NA * 4;
-        case IGF2_CFG_64x256: return Fwd2Cfg<IGF2_CFG_64x256>::NA * 4;
+#define CASE(C) case C: return Fwd2Cfg<C>::NA * Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::WPX;
+        CASE(IGF2_CFG_128x256)
+        CASE(IGF2_CFG_64x512)
+        CASE(IGF2_CFG_128x128)
+        CASE(IGF2_CFG_64x256)
+        CASE(IGF2_CFG_128x256_W4)
+        CASE(IGF2_CFG_64x512_W4)
+#undef CASE
     }
     return 0;
 }
@@ -382,7 +423,7 @@ static hipError_t launch2_one(const IgFwdParams& p, int gx, int gy, hipStream_t 
         if (e != hipSuccess) return e;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(C::WCO * C::WPX * 64), lds, st, p);
     return hipGetLastError();
 }
 template <int CFG>
@@ -400,6 +441,8 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int gx, in
         case IGF2_CFG_64x512: return launch2_cfg<IGF2_CFG_64x512>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x128: return launch2_cfg<IGF2_CFG_128x128>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x256: return launch2_cfg<IGF2_CFG_64x256>(ntap, p, gx, gy, st);
+        case IGF2_CFG_128x256_W4: return launch2_cfg<IGF2_CFG_128x256_W4>(ntap, p, gx, gy, st);
+        case IGF2_CFG_64x512_W4: return launch2_cfg<IGF2_CFG_64x512_W4>(ntap, p, gx, gy, st);
     }
     return hipErrorInvalidValue;
 }
