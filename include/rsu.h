@@ -68,6 +68,21 @@ int rsu_pack_convT_fwd(const float* k_hwoi, void* packed, int Cin, int Cout, rsu
 /* transposed conv backward-data: A[a*2+b][ci][co] */
 int rsu_pack_convT_bwd(const float* k_hwoi, void* packed, int Cin, int Cout, rsu_stream_t stream);
 
+/* Batched packing: every weight tensor of the network re-packed by ONE kernel launch (the per-tensor calls above cost a
+ * launch each, ~64 per optimizer step). Fill a host table with rsu_pack_table_add (same arguments as the per-tensor
+ * calls, selected by `kind`), copy it to the device once (the pointers are static), then call rsu_pack_table_run after
+ * every optimizer step. Returns the number of table entries used by the tensor (4 for RSU_PACK_CONVT_FWD, else 1). */
+#define RSU_PACK_CONV_FWD 0
+#define RSU_PACK_CONV_BWD 1
+#define RSU_PACK_CONVT_FWD 2
+#define RSU_PACK_CONVT_BWD 3
+#define RSU_PACK_CONV_FIRST 4
+size_t rsu_pack_table_entry_bytes(void);
+int rsu_pack_table_add(void* host_table, int index, int kind, const float* w, void* packed, int k, int Cin_total, int ci_off,
+                       int ci_cnt, int Cout, const int* seg_c, int nseg);
+int rsu_pack_table_finish(void* host_table, int nentries, int* total_blocks);
+int rsu_pack_table_run(const void* dev_table, int nentries, int total_blocks, rsu_stream_t stream);
+
 /* ---- network head / tail (VALU kernels) -------------------------------------------------- */
 /* unet.py:22-23  net = conv1x1(X - 0.5) (color_space_adjust). x: f32 [npix][3].
  * out16: bf16 [npix][16] = {net0[0..2], 0, (x-0.5)[0..2], 0, 0 x 8} -- channels 0..2 feed the first
@@ -75,15 +90,19 @@ int rsu_pack_convT_bwd(const float* k_hwoi, void* packed, int Cin, int Cout, rsu
 int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix,
                          rsu_stream_t stream);
 /* unet.py:34-35,42-43 first 3x3 conv of level 0 (Cin = 3) + bias + ReLU, dil = 1 or 2 (dilated branch).
- * in16 as above [N][H][W][16]; w f32 HWIO [3][3][3][Cout]; y bf16 [N][H-2d][W-2d][Cout]. */
-int rsu_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout,
+ * in16 as above [N][H][W][16]; packed = rsu_pack_conv_first(w f32 HWIO [3][3][3][Cout]) (rows for channels 3..15 are
+ * zero, so the (x-0.5) copy in channels 4..6 does not contribute); y bf16 [N][H-2d][W-2d][Cout]. */
+size_t rsu_packed_first_bytes(int Cout);
+int rsu_pack_conv_first(const float* w_hwio, void* packed, int Cout, rsu_stream_t stream);
+int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout,
                        int dil, rsu_stream_t stream);
 /* weight/bias gradients of that conv and, through it, of color_space_adjust:
  * dw1 [3][3][3][Cout], gxc [3][3][3][Cout] where gxc[t][ci][co] = sum_pix (x-0.5)[pix+t][ci] dz[pix][co].
  * ws: float workspace of rsu_conv_first_bwd_ws_floats() floats. */
 size_t rsu_conv_first_bwd_ws_floats(int Cout);
-int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* ws, int N, int H,
-                              int W, int Cout, int dil, rsu_stream_t stream);
+/* db (optional): BiasAddGrad of this conv, computed by the same launch */
+int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N,
+                              int H, int W, int Cout, int dil, rsu_stream_t stream);
 /* unet.py:95 weight_output 1x1 conv (C -> 2) fused with tf_aerial_images.py:147-148 softmax[...,1].
  * act bf16 [npix][C]; w f32 [C][2]; prob f32 [npix]; logits f32 [npix][2] or NULL (unet.forward's return value). */
 int rsu_head_fwd(const void* act, const float* w, const float* b, float* prob, float* logits, long npix, int C,
@@ -114,7 +133,9 @@ int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const 
  * dw f32 HWIO [3][3][Cin_total][Cout] (only those rows are written). (Ho, Wo) = size of dz.
  * ws: rsu_conv2d_bwd_weight_ws_floats() floats of scratch (split-K slabs). */
 size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout);
-int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* ws, int N, int Ho, int Wo,
+/* db (optional, f32 [Cout]): BiasAddGrad = sum over pixels of dz, computed by the same launch (one extra MFMA per
+ * 32-pixel step); pass it with ONE of the sources of a concatenated input, NULL with the others. */
+int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
                           int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream);
 /* BiasAddGrad: db[c] = sum over npix of dz[pix][c]. ws: rsu_bias_grad_ws_floats(npix, C) floats. */
 size_t rsu_bias_grad_ws_floats(long npix, int C);

@@ -266,8 +266,7 @@ def forward(params, X, num_layers, root_size, dilated_layers, emulate_bf16=False
     for i in range(num_layers):
         inp = net
         cache["in_%d" % i] = inp
-        # level-0 conv1 (Cin=3) runs in fp32 VALU with fp32 weights in the HIP path: no weight rounding there
-        first = (i == 0)
+        first = False  # (level-0 conv1 also runs on the MFMA kernel with bf16 weight copies)
         dil_out = None
         last = (i == num_layers - 1)
         if dilated_layers and not last:  # the level L-1 dilated pair is dead code (unet.py:57-59)

@@ -29,17 +29,23 @@ SIGNATURES = {
     "rsu_pack_conv_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_pack_convT_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
     "rsu_pack_convT_bwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "rsu_pack_table_entry_bytes": (_sz, []),
+    "rsu_pack_table_add": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _PI, _i]),
+    "rsu_pack_table_finish": (_i, [_vp, _i, _PI]),
+    "rsu_pack_table_run": (_i, [_vp, _i, _i, _vp]),
     "rsu_color_adjust_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
+    "rsu_packed_first_bytes": (_sz, [_i]),
+    "rsu_pack_conv_first": (_i, [_vp, _vp, _i, _vp]),
     "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv_first_bwd_ws_floats": (_sz, [_i]),
-    "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     "rsu_head_ws_floats": (_sz, [_l, _i]),
     "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
-    "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
     "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

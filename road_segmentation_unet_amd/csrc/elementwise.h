@@ -23,6 +23,9 @@ hipError_t ew_head(bool train, const void* act, const float* w, const float* b, 
                    float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st);
 hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, hipStream_t st);
 hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_t st);
+struct PackJob { PackParams pp; const float* src; bf16_t* dst; int block_start; int pad_; };
+hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t st);
+int ew_pack_blocks(const PackParams& pp);
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st);

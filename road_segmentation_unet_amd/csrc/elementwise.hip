@@ -429,9 +429,9 @@ __global__ void k_momentum(float* __restrict__ w, float* __restrict__ acc, const
 //   k runs over the 32-padded concatenation of the K segments (concat sources)
 // value = src[tapmap(tap)*s_tap + row*s_row + kreal*s_k]
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pack(const float* __restrict__ src, bf16_t* __restrict__ dst, PackParams pp) {
+__device__ __forceinline__ void pack_range(const float* __restrict__ src, bf16_t* __restrict__ dst, const PackParams& pp, long e0, long estride) {
     const long total = (long)pp.nchunks * pp.ntap * pp.ntiles * 512;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    for (long e = e0; e < total; e += estride) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         long r = e >> 9;
         const int T = (int)(r % pp.ntiles);
@@ -457,6 +457,56 @@ __global__ void k_pack(const float* __restrict__ src, bf16_t* __restrict__ dst, 
             v = src[(long)tsrc * pp.s_tap + (long)row * pp.s_row + (long)kreal * pp.s_k];
         }
         dst[e] = f2bf(v);
+    }
+}
+__global__ void k_pack(const float* __restrict__ src, bf16_t* __restrict__ dst, PackParams pp) {
+    pack_range(src, dst, pp, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// all weight tensors of the network in ONE launch: each job owns a contiguous range of blocks (PACK_EPB elements per block)
+#define PACK_EPB 4096
+__global__ void __launch_bounds__(256) k_pack_many(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ int sj;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {  // last job whose block_start <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sj = lo;
+    }
+    __syncthreads();
+    const PackJob jb = jobs[sj];
+    const long total = (long)jb.pp.nchunks * jb.pp.ntap * jb.pp.ntiles * 512;
+    const long b0 = (long)(blockIdx.x - jb.block_start) * PACK_EPB;
+    long hi = b0 + PACK_EPB;
+    if (hi > total) hi = total;
+    PackParams pp = jb.pp;
+    // restrict the generic loop to this block's slice by faking the total through the stride trick: walk the slice directly
+    for (long e = b0 + threadIdx.x; e < hi; e += 256) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        long r = e >> 9;
+        const int T = (int)(r % pp.ntiles);
+        r /= pp.ntiles;
+        const int tap = (int)(r % pp.ntap), chunk = (int)(r / pp.ntap);
+        const int rho = lane & 15;
+        const int row = 32 * (T >> 1) + 8 * (rho >> 2) + 4 * (T & 1) + (rho & 3);
+        const int k = chunk * 32 + 8 * (lane >> 4) + j;
+        int kreal = -1, base_pad = 0, base_real = 0;
+        for (int sgi = 0; sgi < pp.nseg; ++sgi) {
+            const int cpad = (pp.seg_c[sgi] + 31) & ~31;
+            if (k >= base_pad && k < base_pad + cpad) {
+                const int c = k - base_pad;
+                if (c < pp.seg_c[sgi]) kreal = base_real + c;
+            }
+            base_pad += cpad;
+            base_real += pp.seg_c[sgi];
+        }
+        float v = 0.f;
+        if (kreal >= 0 && row < pp.rows) {
+            const int tsrc = pp.flip ? (pp.ntap - 1 - tap) : tap;
+            v = jb.src[(long)tsrc * pp.s_tap + (long)row * pp.s_row + (long)kreal * pp.s_k];
+        }
+        jb.dst[e] = f2bf(v);
     }
 }
 
@@ -603,6 +653,14 @@ hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu,
 hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_t st) {
     const long total = (long)pp.nchunks * pp.ntap * pp.ntiles * 512;
     hipLaunchKernelGGL(k_pack, dim3(grid_for(total, 256)), dim3(256), 0, st, src, (bf16_t*)dst, pp);
+    return hipGetLastError();
+}
+int ew_pack_blocks(const PackParams& pp) {
+    const long total = (long)pp.nchunks * pp.ntap * pp.ntiles * 512;
+    return (int)((total + PACK_EPB - 1) / PACK_EPB);
+}
+hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_many, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
     return hipGetLastError();
 }
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st) {

@@ -63,6 +63,7 @@ struct IgWgradParams {
     int Hf, Wf, Cf;     // F tensor [N][Hf][Wf][Cf]; the pixel grid of the reduction
     IgSrc S;
     float* slab;        // [nsplit][ntap][CsOut][CfOut]
+    float* bslab;       // [nsplit][CfOut] per-split column sums of F (BiasAddGrad when F = dz), or null
     int CsOut, CfOut, cs_off;
     const void* zero_page;
     int N, dil, stride;

@@ -57,6 +57,13 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
             for (int b = 0; b < CST; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // BiasAddGrad rides along: sum_pix F[pix][cf] = F^T x ones, one extra MFMA per k-step in the waves of cs block 0
+    const bool do_bias = (p.bslab != nullptr) && (csb == 0) && (wcs == 0);
+    f32x4 accb[CFT];
+#pragma unroll
+    for (int a = 0; a < CFT; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+
     // per-lane byte offsets of the transposed LDS reads (workgroup constants)
     int foff[TMK / 32][2][CFT];       // F tile: [k-step][read][cf tile]
     int soff[TMK / 32][2][KW][CST];   // S halo tile: [k-step][read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
@@ -191,11 +198,22 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
                 for (int st = 0; st < CST; ++st)
                     acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
+            if (tap == 0 && do_bias) {
+#pragma unroll
+                for (int ct = 0; ct < CFT; ++ct) accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], ones, accb[ct], 0, 0, 0);
+            }
         }
         __syncthreads();
         buf ^= 1;
     }
 
+    if (do_bias && l15 == 0) {  // every column of accb holds the same sums: column 0 writes them
+#pragma unroll
+        for (int ct = 0; ct < CFT; ++ct) {
+            const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
+            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)z * p.CfOut + cf) = accb[ct];
+        }
+    }
     // ---- write this split's slab: D rows = cf (4 consecutive per lane), cols = cs
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap)

@@ -134,6 +134,20 @@ static int kpad_total(const int* seg_c, int nseg) {
 extern "C" size_t rsu_packed_bytes(int taps, int rows, const int* seg_c, int nseg) {
     return (size_t)taps * kpad_total(seg_c, nseg) * rup(rows, 128) * 2;
 }
+static int make_pack(PackParams& pp, int ntap, int rows, const int* seg_c, int nseg, long s_tap, long s_row, long s_k, int flip) {
+    if (nseg < 1 || nseg > 3) return RSU_EINVAL;
+    pp.nchunks = kpad_total(seg_c, nseg) / 32;
+    pp.ntap = ntap;
+    pp.ntiles = rup(rows, 128) / 16;
+    pp.rows = rows;
+    pp.nseg = nseg;
+    for (int i = 0; i < 3; ++i) pp.seg_c[i] = i < nseg ? seg_c[i] : 0;
+    pp.s_tap = s_tap;
+    pp.s_row = s_row;
+    pp.s_k = s_k;
+    pp.flip = flip;
+    return RSU_OK;
+}
 static int do_pack(const float* src, void* dst, int ntap, int rows, const int* seg_c, int nseg, long s_tap, long s_row, long s_k,
                    int flip, hipStream_t st) {
     if (!src || !dst || nseg < 1 || nseg > 3) return RSU_EINVAL;
@@ -183,6 +197,68 @@ extern "C" int rsu_pack_convT_bwd(const float* K, void* packed, int Cin, int Cou
     return do_pack(K, packed, 4, Cin, seg, 1, (long)Cout * Cin, 1, Cin, 0, (hipStream_t)stream);
 }
 
+// ---- batched packing table
+extern "C" size_t rsu_pack_table_entry_bytes(void) { return sizeof(PackJob); }
+extern "C" int rsu_pack_table_add(void* host_table, int index, int kind, const float* w, void* packed, int k, int Cin_total, int ci_off,
+                                  int ci_cnt, int Cout, const int* seg_c, int nseg) {
+    if (!host_table || !w || !packed || index < 0) return RSU_EINVAL;
+    PackJob* t = (PackJob*)host_table + index;
+    int one[1];
+    int rc = RSU_EINVAL, used = 1;
+    memset(t, 0, sizeof(PackJob));
+    t->src = w;
+    t->dst = (bf16_t*)packed;
+    switch (kind) {
+        case RSU_PACK_CONV_FWD:
+            one[0] = Cin_total;
+            if (!seg_c) { seg_c = one; nseg = 1; }
+            rc = make_pack(t->pp, k * k, Cout, seg_c, nseg, (long)Cin_total * Cout, 1, Cout, 0);
+            break;
+        case RSU_PACK_CONV_BWD:
+            one[0] = Cout;
+            t->src = w + (long)ci_off * Cout;
+            rc = make_pack(t->pp, k * k, ci_cnt, one, 1, (long)Cin_total * Cout, Cout, 1, 1);
+            break;
+        case RSU_PACK_CONVT_FWD: {
+            one[0] = Cin_total;
+            const size_t per = rsu_packed_bytes(1, Cout, one, 1);
+            for (int ab = 0; ab < 4; ++ab) {
+                memset(t + ab, 0, sizeof(PackJob));
+                t[ab].src = w + (long)ab * Cout * Cin_total;
+                t[ab].dst = (bf16_t*)((char*)packed + ab * per);
+                rc = make_pack(t[ab].pp, 1, Cout, one, 1, 0, Cin_total, 1, 0);
+            }
+            used = 4;
+            break;
+        }
+        case RSU_PACK_CONVT_BWD:
+            one[0] = Cout;
+            rc = make_pack(t->pp, 4, Cin_total, one, 1, (long)Cout * Cin_total, 1, Cin_total, 0);
+            break;
+        case RSU_PACK_CONV_FIRST:
+            one[0] = 3;
+            rc = make_pack(t->pp, 9, Cout, one, 1, (long)3 * Cout, 1, Cout, 0);
+            break;
+    }
+    return rc == RSU_OK ? used : rc;
+}
+extern "C" int rsu_pack_table_finish(void* host_table, int nentries, int* total_blocks) {
+    if (!host_table || nentries < 1 || !total_blocks) return RSU_EINVAL;
+    PackJob* t = (PackJob*)host_table;
+    int b = 0;
+    for (int i = 0; i < nentries; ++i) {
+        t[i].block_start = b;
+        b += ew_pack_blocks(t[i].pp);
+    }
+    *total_blocks = b;
+    return RSU_OK;
+}
+extern "C" int rsu_pack_table_run(const void* dev_table, int nentries, int total_blocks, rsu_stream_t stream) {
+    if (!dev_table || nentries < 1 || total_blocks < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_pack_many((const PackJob*)dev_table, nentries, total_blocks, (hipStream_t)stream));
+    return RSU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // VALU head / tail
 // ---------------------------------------------------------------------------------------------
@@ -191,13 +267,6 @@ extern "C" int rsu_color_adjust_fwd(const float* x, const float* w, const float*
     HIP_CHECK_RET(ew_color_adjust(x, w, b, out16, npix, (hipStream_t)stream));
     return RSU_OK;
 }
-extern "C" int rsu_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil,
-                                  rsu_stream_t stream) {
-    if (!in16 || !w || !y || Cout % 8 || Cout > 512 || H <= 2 * dil || W <= 2 * dil || (dil != 1 && dil != 2)) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_conv_first_fwd(in16, w, b, y, N, H, W, Cout, dil, (hipStream_t)stream));
-    return RSU_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // igemm_fwd family
 // ---------------------------------------------------------------------------------------------
@@ -333,6 +402,24 @@ extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packe
                    Ho, Wo, 1, 1, relu, 0, (hipStream_t)stream);
 }
 
+extern "C" size_t rsu_packed_first_bytes(int Cout) {
+    int seg[1] = {3};
+    return rsu_packed_bytes(9, Cout, seg, 1);
+}
+extern "C" int rsu_pack_conv_first(const float* w, void* packed, int Cout, rsu_stream_t stream) {
+    int seg[1] = {3};
+    return do_pack(w, packed, 9, Cout, seg, 1, (long)3 * Cout, 1, Cout, 0, (hipStream_t)stream);
+}
+extern "C" int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout, int dil,
+                                  rsu_stream_t stream) {
+    if (!in16 || !packed || !y || Cout % 8 || H <= 2 * dil || W <= 2 * dil + 1 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
+    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    return run_fwd(&s, 1, packed, 0, rup(Cout, 128) / 16, 0, b, y, nullptr, N, H, W, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0, Ho, Wo, 1, 1, 1, 0,
+                   (hipStream_t)stream);
+}
+
 extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
                                    int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, rsu_stream_t stream) {
     if (!dz || !packed_bwd || !dx || Cout % 8 || ci_cnt % 8 || ci_off % 32 || ci_off + ci_cnt > Cin_total || (dil != 1 && dil != 2))
@@ -390,7 +477,7 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
 }
 
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
-                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st) {
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr) {
     WgPlan pl;
     if (!plan_wgrad(pl, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
     IgWgradParams p;
@@ -400,6 +487,7 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.S.ptr = (const bf16_t*)S->ptr;
     p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
     p.slab = ws;
+    p.bslab = db ? ws + (size_t)pl.nsplit * ntap * CsOut * CfOut : nullptr;
     p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
@@ -410,19 +498,20 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.g = pl.g;
     HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
     HIP_CHECK_RET(ew_reduce_slabs(ws, out, pl.nsplit, ntap, CsOut, cs_off, S->C, CfOut, st));
+    if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, pl.nsplit, 1, 1, 0, 1, CfOut, st));
     return RSU_OK;
 }
 
 extern "C" size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout) {
-    return (size_t)wgrad_max_split(Cout, src_C, 64) * 9 * Cin_total * Cout;
+    return (size_t)wgrad_max_split(Cout, src_C, 64) * (9 * (size_t)Cin_total * Cout + Cout);
 }
-extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* ws, int N, int Ho, int Wo, int Cin_total,
-                                     int ci_off, int Cout, int dil, rsu_stream_t stream) {
+extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
+                                     int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream) {
     if (!src || !src->ptr || !dz || !dw || !ws || src->C % 8 || Cout % 8 || ci_off + src->C > Cin_total || (dil != 1 && dil != 2))
         return RSU_EINVAL;
     if (src->oy < 0 || src->ox < 0 || src->oy + Ho + 2 * dil > src->H || src->ox + Wo + 2 * dil > src->W || Wo < 2) return RSU_EINVAL;
     // F = dz (cf = co), S = layer input (cs = ci): slab[tap][ci][co] = HWIO
-    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, (hipStream_t)stream);
+    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, (hipStream_t)stream, db);
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
@@ -438,16 +527,16 @@ extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK,
 }
 
 extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {
-    return (size_t)(wgrad_max_split(Cout, 16, 16) + 1) * 9 * 16 * Cout;
+    return (size_t)(wgrad_max_split(Cout, 16, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
 }
-extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* ws, int N, int H, int W, int Cout,
-                                         int dil, rsu_stream_t stream) {
+extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N, int H, int W,
+                                         int Cout, int dil, rsu_stream_t stream) {
     if (!in16 || !dz || !dw1 || !ws || Cout % 8 || (dil != 1 && dil != 2) || W - 2 * dil < 2) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
     float* tmp = ws;                          // [9][16][Cout]
     float* slabs = ws + (size_t)9 * 16 * Cout;
-    int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, (hipStream_t)stream);
+    int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, (hipStream_t)stream, db);
     if (rc) return rc;
     HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));
     return RSU_OK;

@@ -220,40 +220,54 @@ class UNet:
 
     # ------------------------------------------------------------------ packed bf16 weights
     def repack(self):
-        """float32 master weights -> bf16 MFMA fragment order (after init / load / every optimizer step)."""
+        """float32 master weights -> bf16 MFMA fragment order (after init / load / every optimizer step): ONE kernel launch
+        over a device-resident job table (rsu_pack_table_*) built on first use."""
         lib = _lib.lib()
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
-        first = not hasattr(self, "pk")
-        if first:
+        if not hasattr(self, "pk"):
             self.pk = {}
-        for n, (_, _, s) in self._slices.items():
-            if not n.endswith("kernel") or _is_dead(n, self.L):
-                continue
-            if n.startswith("up_conv"):
-                cout, cin = s[2], s[3]
-                if first:
-                    seg = (ctypes.c_int * 1)(cin)
-                    self.pk[n, "fwd"] = torch.zeros(4 * lib.rsu_packed_bytes(1, cout, seg, 1) // 2, dtype=torch.bfloat16, device=self.device)
-                    seg = (ctypes.c_int * 1)(cout)
-                    self.pk[n, "bwd"] = torch.zeros(lib.rsu_packed_bytes(4, cin, seg, 1) // 2, dtype=torch.bfloat16, device=self.device)
-                call("rsu_pack_convT_fwd", _ptr(self.w[n]), _ptr(self.pk[n, "fwd"]), cin, cout, st)
-                if self.training:
-                    call("rsu_pack_convT_bwd", _ptr(self.w[n]), _ptr(self.pk[n, "bwd"]), cin, cout, st)
-            elif s[0] == 3 and s[2] != NUM_CHANNELS:
-                cin, cout = s[2], s[3]
-                segs = self._conv_sources_c(n, s)
-                seg = (ctypes.c_int * len(segs))(*segs)
-                if first:
-                    self.pk[n, "fwd"] = torch.zeros(lib.rsu_packed_bytes(9, cout, seg, len(segs)) // 2, dtype=torch.bfloat16, device=self.device)
-                    seg1 = (ctypes.c_int * 1)(cout)
-                    for si, c in enumerate(segs):  # one backward-data pack per concat source
-                        self.pk[n, "bwd", si] = torch.zeros(lib.rsu_packed_bytes(9, c, seg1, 1) // 2, dtype=torch.bfloat16, device=self.device)
-                call("rsu_pack_conv_fwd", _ptr(self.w[n]), _ptr(self.pk[n, "fwd"]), 3, cin, cout, seg, len(segs), st)
-                if self.training:
+            jobs = []  # (kind, weight name, packed tensor, k, Cin_total, ci_off, ci_cnt, Cout, segs)
+
+            def buf(nbytes):
+                return torch.zeros(nbytes // 2, dtype=torch.bfloat16, device=self.device)
+            for n, (_, _, s) in self._slices.items():
+                if not n.endswith("kernel") or _is_dead(n, self.L):
+                    continue
+                if n.startswith("up_conv"):
+                    cout, cin = s[2], s[3]
+                    self.pk[n, "fwd"] = buf(4 * lib.rsu_packed_bytes(1, cout, (ctypes.c_int * 1)(cin), 1))
+                    self.pk[n, "bwd"] = buf(lib.rsu_packed_bytes(4, cin, (ctypes.c_int * 1)(cout), 1))
+                    jobs.append((2, n, self.pk[n, "fwd"], 2, cin, 0, cin, cout, None))
+                    if self.training:
+                        jobs.append((3, n, self.pk[n, "bwd"], 2, cin, 0, cin, cout, None))
+                elif s[0] == 3 and s[2] == NUM_CHANNELS:  # level-0 conv1 / atrous_conv1 over the 16-channel input tensor
+                    self.pk[n, "fwd"] = buf(lib.rsu_packed_first_bytes(s[3]))
+                    jobs.append((4, n, self.pk[n, "fwd"], 3, 3, 0, 3, s[3], None))
+                elif s[0] == 3:
+                    cin, cout = s[2], s[3]
+                    segs = self._conv_sources_c(n, s)
+                    self.pk[n, "fwd"] = buf(lib.rsu_packed_bytes(9, cout, (ctypes.c_int * len(segs))(*segs), len(segs)))
+                    jobs.append((0, n, self.pk[n, "fwd"], 3, cin, 0, cin, cout, segs))
                     off = 0
-                    for si, c in enumerate(segs):
-                        call("rsu_pack_conv_bwd", _ptr(self.w[n]), _ptr(self.pk[n, "bwd", si]), 3, cin, off, c, cout, st)
+                    for si, c in enumerate(segs):  # one backward-data pack per concat source
+                        self.pk[n, "bwd", si] = buf(lib.rsu_packed_bytes(9, c, (ctypes.c_int * 1)(cout), 1))
+                        if self.training:
+                            jobs.append((1, n, self.pk[n, "bwd", si], 3, cin, off, c, cout, None))
                         off += c
+            esz = lib.rsu_pack_table_entry_bytes()
+            host = ctypes.create_string_buffer(esz * (len(jobs) + 3 * sum(1 for j in jobs if j[0] == 2)))
+            idx = 0
+            for kind, n, packed, k, cin, off, cnt, cout, segs in jobs:
+                seg = (ctypes.c_int * len(segs))(*segs) if segs else None
+                used = lib.rsu_pack_table_add(host, idx, kind, _ptr(self.w[n]), _ptr(packed), k, cin, off, cnt, cout, seg, len(segs) if segs else 0)
+                if used < 1:
+                    raise _lib.RsuError("rsu_pack_table_add(%s) failed: %d" % (n, used))
+                idx += used
+            nb = ctypes.c_int(0)
+            _lib.check(lib.rsu_pack_table_finish(host, idx, ctypes.byref(nb)), "rsu_pack_table_finish")
+            self._pack_n, self._pack_blocks = idx, nb.value
+            self._pack_table = torch.frombuffer(bytearray(host.raw[:esz * idx]), dtype=torch.uint8).to(self.device)
+        call("rsu_pack_table_run", _ptr(self._pack_table), self._pack_n, self._pack_blocks, st)
 
     # ------------------------------------------------------------------ forward
     def _stream(self):
@@ -293,13 +307,13 @@ class UNet:
             last = i == L - 1
             if self.dilated and not last:
                 if i == 0:
-                    call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.w["conv_dilut_0/atrous_conv1/kernel"]),
+                    call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_dilut_0/atrous_conv1/kernel", "fwd"]),
                          _ptr(self.w["conv_dilut_0/atrous_conv1/bias"]), _ptr(a["d1_0"]), B, h, h, self.root, 2, st)
                 else:
                     self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
                 self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
             if i == 0:
-                call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.w["conv_0/conv1/kernel"]), _ptr(self.w["conv_0/conv1/bias"]),
+                call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_0/conv1/kernel", "fwd"]), _ptr(self.w["conv_0/conv1/bias"]),
                      _ptr(a["c1_0"]), B, h, h, self.root, 1, st)
             else:
                 self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i])
@@ -336,10 +350,10 @@ class UNet:
         off = 0
         for t, win in srcs_t:
             s = _src(t, win, win)
+            db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
             self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
-                        _ptr(dz), _ptr(self.g[name + "/kernel"]), _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
+                        _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
             off += t.shape[3]
-        call("rsu_bias_grad", _ptr(dz), _ptr(self.g[name + "/bias"]), _ptr(self.ws), self.B * hout * hout, cout, st)
 
     def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
         """Conv2DBackpropInput towards concat source `src_index` of conv `name` (its own weight pack)"""
@@ -402,8 +416,7 @@ class UNet:
                 self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
             else:
                 call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
-                     _ptr(self.ws), B, h, h, nf, 1, st)
-                call("rsu_bias_grad", _ptr(dz1), _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B * (h - 2) * (h - 2), nf, st)
+                     _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B, h, h, nf, 1, st)
             if self.dilated and i < L - 1:
                 d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
@@ -418,8 +431,7 @@ class UNet:
                     self._bwd_data("conv_dilut_%d/atrous_conv1" % i, dzd1, g["pool_%d" % (i - 1)], h, accumulate=1, dil=2)
                 else:
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
-                         _ptr(self.gfirst[1]), _ptr(self.ws), B, h, h, nf, 2, st)
-                    call("rsu_bias_grad", _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B * (h - 4) * (h - 4), nf, st)
+                         _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, st)
             if i > 0:
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if self.dilated else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)

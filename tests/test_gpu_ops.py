@@ -138,9 +138,11 @@ def test_conv2d_bwd_weight_and_bias(N, H, W, Cin, Cout, dil):
     ws = torch.zeros(max(lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout), lib().rsu_bias_grad_ws_floats(N * Ho * Wo, Cout)),
                      dtype=torch.float32, device=hu.DEV)
     s = hu.src_of(xd, H, W)
-    call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
+    db2 = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+    call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db2), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
     ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=dil)
     hu.assert_f32_close(hu.host(dw), ref_dw, "conv2d_bwd_weight")
+    hu.assert_f32_close(hu.host(db2), ref_db, "bias grad fused in wgrad")
     if 256 % (Cout // 8) == 0:
         call("rsu_bias_grad", hu.ptr(dzd), hu.ptr(db), hu.ptr(ws), N * Ho * Wo, Cout, hu.stream())
         hu.assert_f32_close(hu.host(db), ref_db, "bias_grad")
@@ -156,7 +158,7 @@ def test_conv2d_bwd_weight_cropped_sources():
     ws = torch.zeros(lib().rsu_conv2d_bwd_weight_ws_floats(96, 32, 64), dtype=torch.float32, device=hu.DEV)
     for t, off in [(ad, 0), (cd, 32)]:
         s = hu.src_of(t, h, h)
-        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(ws), N, h - 2, h - 2, 96, off, 64, 1, hu.stream())
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), None, hu.ptr(ws), N, h - 2, h - 2, 96, off, 64, 1, hu.stream())
     cat = np.concatenate([U.center_crop(a, h, h), c], axis=3)
     hu.assert_f32_close(hu.host(dw), U.conv2d_bwd_weight(cat, dz)[0], "bwd_weight 2 cropped sources")
 
@@ -181,8 +183,10 @@ def test_color_adjust_and_first_conv(dil):
     assert not got16[..., 3].any() and not got16[..., 7:].any()
     Ho, Wo = H - 2 * dil, W - 2 * dil
     y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(w1d), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, hu.stream())
-    ref = U.conv2d_fwd(got16[..., 0:3], w1, b1, dil=dil)  # fp32 weights on purpose: VALU kernel
+    pk1 = torch.zeros(lib().rsu_packed_first_bytes(Cout) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_pack_conv_first", hu.ptr(w1d), hu.ptr(pk1), Cout, hu.stream())
+    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, hu.stream())
+    ref = U.conv2d_fwd(got16[..., 0:3], hu.q(w1), b1, dil=dil)
     hu.assert_bf16_close(hu.host(y), ref, "conv_first_fwd")
     # weight gradients (MFMA narrow wgrad over the 16-channel tensor)
     dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
@@ -190,7 +194,9 @@ def test_color_adjust_and_first_conv(dil):
     gxc = torch.zeros((3, 3, 3, Cout), dtype=torch.float32, device=hu.DEV)
     ws = torch.zeros(lib().rsu_conv_first_bwd_ws_floats(Cout), dtype=torch.float32, device=hu.DEV)
     dzd = hu.dev_bf16(dz)
-    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gxc), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
+    dbf = torch.zeros(Cout, dtype=torch.float32, device=hu.DEV)
+    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gxc), hu.ptr(dbf), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
+    hu.assert_f32_close(hu.host(dbf), dz.reshape(-1, Cout).astype(np.float64).sum(0), "conv_first db")
     hu.assert_f32_close(hu.host(dw1), U.conv2d_bwd_weight(got16[..., 0:3], dz, dil=dil)[0], "conv_first dW")
     hu.assert_f32_close(hu.host(gxc), U.conv2d_bwd_weight(got16[..., 4:7], dz, dil=dil)[0], "conv_first gxc")
 

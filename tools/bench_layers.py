@@ -107,7 +107,7 @@ def main():
                     elif op == "bwd":
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, st))
                     else:
-                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
+                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
                     line += " %s%s %6.0fus %5.0fTF |" % (op, "" if cfg < 0 else "[%d]" % cfg, t * 1e6, fl / t / 1e12)
                     tot[(op, cfg)] = tot.get((op, cfg), 0.0) + t
                 except Exception as ex:

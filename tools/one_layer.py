@@ -35,5 +35,5 @@ for _ in range(reps):
     elif op == "bwd":
         call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, H, H, cin, 0, cin, cout, dil, st)
     else:
-        call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(ws), B, ho, ho, cin, 0, cout, dil, st)
+        call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, st)
 torch.cuda.synchronize()
