@@ -74,5 +74,6 @@ struct IgWgradParams {
 enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_NCFG = 2 };
 size_t igemm_wgrad_lds_bytes(int cfg, int npix_max);
 int igemm_wgrad_tmk(int cfg);
+int igemm_wgrad_kgroups(int cfg);  // slabs written per grid.z slice
 hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,
                               hipStream_t st);

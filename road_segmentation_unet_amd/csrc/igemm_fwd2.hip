@@ -315,30 +315,31 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                     for (int pt = 0; pt < PT; ++pt)
                         b[pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][kx] + rowoff));
                 };
-                load_tap(0, fa[0], fb[0]);
-                __builtin_amdgcn_sched_barrier(0);  // request the first fragments BEFORE the prefetch bookkeeping below
+                auto prefetch = [&]() {
                 // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
-                if (SPC == 1) {
-                    if (gc + 1 < GC) {
-                        if (c + 1 == nchunks) {
-                            ++pk;
-                            ptile = decode(pk);
-                            prep_a(ptile);
+                    if (SPC == 1) {
+                        if (gc + 1 < GC) {
+                            if (c + 1 == nchunks) {
+                                ++pk;
+                                ptile = decode(pk);
+                                prep_a(ptile);
+                            }
+                            issue_a(gc + 1, ptile);
                         }
-                        issue_a(gc + 1, ptile);
-                    }
-                    if (st + 2 < GC * SPC) issue_w();
-                } else {
-                    if (st + 2 < GC * SPC) issue_w();
-                    if (j == 0 && gc + 1 < GC) {
-                        if (c + 1 == nchunks) {
-                            ++pk;
-                            ptile = decode(pk);
-                            prep_a(ptile);
+                        if (st + 2 < GC * SPC) issue_w();
+                    } else {
+                        if (st + 2 < GC * SPC) issue_w();
+                        if (j == 0 && gc + 1 < GC) {
+                            if (c + 1 == nchunks) {
+                                ++pk;
+                                ptile = decode(pk);
+                                prep_a(ptile);
+                            }
+                            issue_a(gc + 1, ptile);
                         }
-                        issue_a(gc + 1, ptile);
                     }
-                }
+                };
+                load_tap(0, fa[0], fb[0]);
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
                     if (tl + 1 < TPS) load_tap(tl + 1, fa[(tl + 1) & 1], fb[(tl + 1) & 1]);
@@ -348,6 +349,15 @@ igemm_fwd2_kernel(const IgFwdParams p) {
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
                             acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tl & 1][ct], fb[tl & 1][pt], acc[ct][pt], 0, 0, 0);
+                    // LDS-DMA bookkeeping for the stages ahead, placed BEHIND a block of MFMAs and staggered between the two
+                    // waves of a SIMD (waves w and w+4): while one does scalar address work its partner feeds the matrix pipe
+                    if (TPS == 1 || NW == 4) {
+                        if (tl == 0) prefetch();
+                    } else {
+                        if (tl == 0 && wave < NW / 2) prefetch();
+                        if (tl == 1 && wave >= NW / 2) prefetch();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
             stage(std::integral_constant<int, 0>{});

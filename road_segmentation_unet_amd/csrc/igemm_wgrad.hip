@@ -22,10 +22,16 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 
 // Tiles are ALIGNED (strip width SW = 2^lsw divides TMK; a tile = TMK/SW full rows of one strip), so every per-lane LDS
 // read offset is a workgroup constant and a pixel tile only contributes scalar bases + edge validity.
-template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK>
-__global__ void __launch_bounds__(WCF* WCS * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// KG = 1: four waves, one per SIMD. KG = 2: eight waves; wave group g = wave/4 reduces k-steps [g*KS/2, (g+1)*KS/2) of every
+// pixel tile into its OWN accumulators and slab (2*nsplit slabs in total), so two waves share each SIMD and cover each
+// other's LDS latency / DMA bookkeeping without any in-kernel reduction.
+template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK, int KG>
+__global__ void __launch_bounds__(WCF* WCS * KG * 64) __attribute__((amdgpu_waves_per_eu(KG, KG)))
 igemm_wgrad_kernel(const IgWgradParams p) {
-    constexpr int NW = WCF * WCS;
+    constexpr int NW = WCF * WCS * KG;
+    constexpr int KS = TMK / 32;          // 32-pixel MFMA steps per tile
+    constexpr int KSG = KS / KG;          // ... per wave group
+    static_assert(KS % KG == 0, "k-steps must split evenly over the wave groups");
     constexpr int CFB = WCF * CFT * 16;  // must be 64
     constexpr int CSB = WCS * CST * 16;  // 64 or 16
     constexpr int KH = NTAP / KW;
@@ -41,9 +47,11 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wcf = wave / WCS, wcs = wave % WCS;
+    const int kgrp = wave / (WCF * WCS), wave4 = wave % (WCF * WCS);
+    const int wcf = wave4 / WCS, wcs = wave4 % WCS;
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
     const int cfb = blockIdx.x, csb = blockIdx.y, z = blockIdx.z;
+    const int zs = z * KG + kgrp;  // slab this wave group accumulates into
     const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TMK >> lsw;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     const int Hs = (p.Hf - 1) * p.stride + (KH - 1) * p.dil + 1;  // S window extent
@@ -65,13 +73,13 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
     // per-lane byte offsets of the transposed LDS reads (workgroup constants)
-    int foff[TMK / 32][2][CFT];       // F tile: [k-step][read][cf tile]
-    int soff[TMK / 32][2][KW][CST];   // S halo tile: [k-step][read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
+    int foff[KSG][2][CFT];       // F tile: [k-step of this group][read][cf tile]
+    int soff[KSG][2][KW][CST];   // S halo tile: [k-step][read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
 #pragma unroll
-    for (int ks = 0; ks < TMK / 32; ++ks)
+    for (int ks = 0; ks < KSG; ++ks)
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
-            const int ml = ks * 32 + rd * 16 + 4 * g4 + q4;
+            const int ml = (kgrp * KSG + ks) * 32 + rd * 16 + 4 * g4 + q4;
 #pragma unroll
             for (int ct = 0; ct < CFT; ++ct) {
                 const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
@@ -180,7 +188,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             }
         };
         // one software-pipelined sequence over (k-step, tap): operands of step+1 are requested before the MFMAs of step
-        constexpr int NS = (TMK / 32) * NTAP;
+        constexpr int NS = KSG * NTAP;
         bf16x8 fa[2][CFT], sv[2][CST];
         load_F(0, fa[0]);
         load_S(0, 0, sv[0]);
@@ -211,7 +219,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
         for (int ct = 0; ct < CFT; ++ct) {
             const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
-            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)z * p.CfOut + cf) = accb[ct];
+            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)zs * p.CfOut + cf) = accb[ct];
         }
     }
     // ---- write this split's slab: D rows = cf (4 consecutive per lane), cols = cs
@@ -225,16 +233,17 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             for (int ct = 0; ct < CFT; ++ct) {
                 const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
                 if (cf >= p.Cf) continue;
-                float* dst = p.slab + (((long)z * NTAP + tap) * p.CsOut + p.cs_off + cs) * p.CfOut + cf;
+                float* dst = p.slab + (((long)zs * NTAP + tap) * p.CsOut + p.cs_off + cs) * p.CfOut + cf;
                 *(f32x4*)dst = acc[tap][ct][st];
             }
         }
 }
 
 template <int CFG> struct WgCfg;
-template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 2, WCS = 2, CFT = 2, CST = 2, TMK = 128; };
-template <> struct WgCfg<IGW_CFG_64x16> { static constexpr int WCF = 4, WCS = 1, CFT = 1, CST = 1, TMK = 128; };
+template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 2, WCS = 2, CFT = 2, CST = 2, TMK = 128, KG = 2; };
+template <> struct WgCfg<IGW_CFG_64x16> { static constexpr int WCF = 4, WCS = 1, CFT = 1, CST = 1, TMK = 128, KG = 2; };
 
+int igemm_wgrad_kgroups(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::KG : WgCfg<IGW_CFG_64x16>::KG; }
 int igemm_wgrad_tmk(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::TMK : WgCfg<IGW_CFG_64x16>::TMK; }
 
 size_t igemm_wgrad_lds_bytes(int cfg, int npix_max) {
@@ -245,7 +254,7 @@ size_t igemm_wgrad_lds_bytes(int cfg, int npix_max) {
 template <int CFG, int NTAP, int KW>
 static hipError_t wlaunch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
     using C = WgCfg<CFG>;
-    auto kern = igemm_wgrad_kernel<C::WCF, C::WCS, C::CFT, C::CST, NTAP, KW, C::TMK>;
+    auto kern = igemm_wgrad_kernel<C::WCF, C::WCS, C::CFT, C::CST, NTAP, KW, C::TMK, C::KG>;
     const size_t lds = igemm_wgrad_lds_bytes(CFG, p.g.npix_max);
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -253,7 +262,7 @@ static hipError_t wlaunch_one(const IgWgradParams& p, int gx, int gy, int gz, hi
         if (e != hipSuccess) return e;
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(C::WCF * C::WCS * 64), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(C::WCF * C::WCS * C::KG * 64), lds, st, p);
     return hipGetLastError();
 }
 

@@ -470,7 +470,9 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
     pl.gx = cdiv(Cf, 64);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
-    const int want = wgrad_max_split(Cf, Cs, csb);
+    const int kg = igemm_wgrad_kgroups(cfg);
+    int want = wgrad_max_split(Cf, Cs, csb) / kg;  // workgroups along z; each writes kg slabs
+    if (want < 1) want = 1;
     pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
     (void)ntap;
     return true;
@@ -487,7 +489,8 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.S.ptr = (const bf16_t*)S->ptr;
     p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
     p.slab = ws;
-    p.bslab = db ? ws + (size_t)pl.nsplit * ntap * CsOut * CfOut : nullptr;
+    const int nslab = pl.nsplit * igemm_wgrad_kgroups(cfg);
+    p.bslab = db ? ws + (size_t)nslab * ntap * CsOut * CfOut : nullptr;
     p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
@@ -497,8 +500,8 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.lsw = pl.lsw;
     p.g = pl.g;
     HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
-    HIP_CHECK_RET(ew_reduce_slabs(ws, out, pl.nsplit, ntap, CsOut, cs_off, S->C, CfOut, st));
-    if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, pl.nsplit, 1, 1, 0, 1, CfOut, st));
+    HIP_CHECK_RET(ew_reduce_slabs(ws, out, nslab, ntap, CsOut, cs_off, S->C, CfOut, st));
+    if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, nslab, 1, 1, 0, 1, CfOut, st));
     return RSU_OK;
 }
 
