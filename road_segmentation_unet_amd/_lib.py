@@ -88,6 +88,17 @@ def check(rc, what):
         raise RsuError("%s failed: rc=%d (hip error %d)" % (what, rc, lib().rsu_last_hip_error()))
 
 
+_TRACE = os.environ.get("RSU_TRACE", "0") == "1"
+
+
 def call(name, *args):
-    """Invoke an int-returning entry point and raise on a non-zero status."""
+    """Invoke an int-returning entry point and raise on a non-zero status. RSU_TRACE=1 prints every call and
+    synchronises the device after it (to locate a faulting launch)."""
+    if _TRACE:
+        import sys
+        import torch
+        print("[rsu]", name, [a if isinstance(a, (int, float)) else "." for a in args], file=sys.stderr, flush=True)
+        check(getattr(lib(), name)(*args), name)
+        torch.cuda.synchronize()
+        return
     check(getattr(lib(), name)(*args), name)

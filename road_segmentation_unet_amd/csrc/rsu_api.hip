@@ -459,6 +459,12 @@ static int wgrad_max_split(int Cf, int Cs, int csb) {
     int want = 512 / (cdiv(Cf, 64) * cdiv(Cs, csb));
     return want < 1 ? 1 : want;
 }
+// slabs a launch may write: (grid.z splits, at least one) x (wave groups of the config, each with its own slab)
+static size_t wgrad_max_slabs(int cfg, int Cf, int Cs, int csb) {
+    const int kg = igemm_wgrad_kgroups(cfg);
+    int z = wgrad_max_split(Cf, Cs, csb) / kg;
+    return (size_t)(z < 1 ? 1 : z) * kg;
+}
 struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw; };
 static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
     pl.cfg = cfg;
@@ -506,7 +512,7 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
 }
 
 extern "C" size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout) {
-    return (size_t)wgrad_max_split(Cout, src_C, 64) * (9 * (size_t)Cin_total * Cout + Cout);
+    return wgrad_max_slabs(IGW_CFG_64x64, Cout, src_C, 64) * (9 * (size_t)Cin_total * Cout + Cout);
 }
 extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
                                      int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream) {
@@ -518,7 +524,7 @@ extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
-    return (size_t)wgrad_max_split(Cin, Cout, 64) * 4 * Cout * Cin;
+    return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout, 64) * 4 * (size_t)Cout * Cin;
 }
 extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin, int Cout,
                                        rsu_stream_t stream) {
@@ -530,7 +536,7 @@ extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK,
 }
 
 extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {
-    return (size_t)(wgrad_max_split(Cout, 16, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
+    return (wgrad_max_slabs(IGW_CFG_64x16, Cout, 16, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
 }
 extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N, int H, int W,
                                          int Cout, int dil, rsu_stream_t stream) {

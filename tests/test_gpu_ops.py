@@ -30,6 +30,7 @@ CONV_SHAPES = [
     (2, 20, 20, 128, 256, 1),
     (1, 150, 140, 64, 64, 1),
     (1, 26, 26, 256, 128, 2),
+    (1, 8, 8, 1536, 1024, 1),  # > 256 weight tiles: fewer grid.z splits than wave groups (workspace sizing)
 ]
 
 
@@ -135,14 +136,16 @@ def test_conv2d_bwd_weight_and_bias(N, H, W, Cin, Cout, dil):
     xd, dzd = hu.dev_bf16(x), hu.dev_bf16(dz)
     dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
     db = torch.zeros(Cout, dtype=torch.float32, device=hu.DEV)
-    ws = torch.zeros(max(lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout), lib().rsu_bias_grad_ws_floats(N * Ho * Wo, Cout)),
-                     dtype=torch.float32, device=hu.DEV)
+    nws = max(lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout), lib().rsu_bias_grad_ws_floats(N * Ho * Wo, Cout))
+    ws = torch.zeros(nws + 4096, dtype=torch.float32, device=hu.DEV)
+    ws[nws:] = 12345.0  # guard band: the kernels must stay inside the advertised workspace
     s = hu.src_of(xd, H, W)
     db2 = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
     call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db2), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
     ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=dil)
     hu.assert_f32_close(hu.host(dw), ref_dw, "conv2d_bwd_weight")
     hu.assert_f32_close(hu.host(db2), ref_db, "bias grad fused in wgrad")
+    assert bool((ws[nws:] == 12345.0).all()), "workspace overrun"
     if 256 % (Cout // 8) == 0:
         call("rsu_bias_grad", hu.ptr(dzd), hu.ptr(db), hu.ptr(ws), N * Ho * Wo, Cout, hu.stream())
         hu.assert_f32_close(hu.host(db), ref_db, "bias_grad")

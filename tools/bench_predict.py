@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Sliding-window ensemble inference timing (BASELINE.json configs[4], c5): 604x604 images, stride 12, 6-way ensemble.
+usage: python tools/bench_predict.py [--L 6 --dilated --images 1 --stride 12 --size 604 --batch 8]"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from road_segmentation_unet_amd.model import ConvolutionalModel, Options
+ap = argparse.ArgumentParser()
+ap.add_argument("--L", type=int, default=6); ap.add_argument("--root", type=int, default=64)
+ap.add_argument("--dilated", action="store_true"); ap.add_argument("--images", type=int, default=1)
+ap.add_argument("--stride", type=int, default=12); ap.add_argument("--size", type=int, default=604)
+ap.add_argument("--batch", type=int, default=8); ap.add_argument("--no_ensemble", action="store_true")
+a = ap.parse_args()
+opts = Options(num_layers=a.L, root_size=a.root, patch_size=388, stride=a.stride, dilated_layers=a.dilated, batch_size=a.batch,
+               ensemble_prediction=not a.no_ensemble, dropout=1.0)
+m = ConvolutionalModel(opts)
+imgs = np.random.RandomState(0).rand(a.images, a.size, a.size, 3).astype(np.float32)
+pps = (a.size - 388) // a.stride + 1
+ntiles = a.images * (1 if a.no_ensemble else 6) * pps * pps
+m.predict(imgs[:1, :412, :412])  # warm-up (small)
+torch.cuda.synchronize(); t0 = time.time()
+masks = m.predict(imgs)
+torch.cuda.synchronize(); dt = time.time() - t0
+print({"tiles": ntiles, "seconds": round(dt, 3), "tiles_per_s": round(ntiles / dt, 1), "images_per_s": round(a.images / dt, 4),
+       "mask_shape": masks.shape, "mask_range": (float(masks.min()), float(masks.max()))})
