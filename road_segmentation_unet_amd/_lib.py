@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsu_hip.so")
+LIB_PATH = os.environ.get("RSU_LIB_PATH") or os.path.join(_HERE, "librsu_hip.so")  # RSU_LIB_PATH: developer A/B of two builds
 
 _vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 

@@ -36,6 +36,7 @@ struct IgFwdParams {
     int relu, accumulate;
     int ncob;
     int lsw;              // log2(g.SW) for the aligned-tile kernels (igemm_fwd2)
+    int dbg;              // developer A/B switch (RSU_FWD_DBG): bit 0 = skip weight staging, bit 1 = skip halo staging (timing only)
     TileGeo g;
 };
 
@@ -69,10 +70,13 @@ struct IgWgradParams {
     int N, dil, stride;
     int nsplit, ntiles_total;
     int lsw;            // log2(g.SW): tiles are aligned (SW divides the pixel tile)
+    int nbuf, nsw;      // staging ring depth (2 or 3) and S pieces per wave per tile (igemm_wgrad_nsw)
+    int dbg;            // developer A/B switch (RSU_WG_DBG): 1 = skip the staging loads of all but the first tile (timing only)
     TileGeo g;          // TM of this geometry = pixels per reduction tile
 };
 enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_NCFG = 2 };
-size_t igemm_wgrad_lds_bytes(int cfg, int npix_max);
+size_t igemm_wgrad_lds_bytes(int cfg, int npix_max, int nbuf);
+int igemm_wgrad_nsw(int cfg, int npix_max);
 int igemm_wgrad_tmk(int cfg);
 int igemm_wgrad_kgroups(int cfg);  // slabs written per grid.z slice
 hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,

@@ -318,7 +318,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 auto prefetch = [&]() {
                 // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
                     if (SPC == 1) {
-                        if (gc + 1 < GC) {
+                        if (gc + 1 < GC && !(p.dbg & 2)) {
                             if (c + 1 == nchunks) {
                                 ++pk;
                                 ptile = decode(pk);
@@ -326,10 +326,10 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                             }
                             issue_a(gc + 1, ptile);
                         }
-                        if (st + 2 < GC * SPC) issue_w();
+                        if (st + 2 < GC * SPC && !(p.dbg & 1)) issue_w();
                     } else {
-                        if (st + 2 < GC * SPC) issue_w();
-                        if (j == 0 && gc + 1 < GC) {
+                        if (st + 2 < GC * SPC && !(p.dbg & 1)) issue_w();
+                        if (j == 0 && gc + 1 < GC && !(p.dbg & 2)) {
                             if (c + 1 == nchunks) {
                                 ++pk;
                                 ptile = decode(pk);
@@ -379,7 +379,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
 template <int CFG> struct Fwd2Cfg;
 // NA = halo DMA pieces per wave per chunk (NA * NW * 16 pixels of halo at most)
 template <> struct Fwd2Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 4; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 5; };
+template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 6; };
 template <> struct Fwd2Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 3; };
 template <> struct Fwd2Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 4; };
 template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8, NA = 7; };

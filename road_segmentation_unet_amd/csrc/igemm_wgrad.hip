@@ -11,20 +11,22 @@
 // is bank-conflict free (tools/lds_bank_sim.py).
 // The S halo tile is staged once per pixel tile and re-used by all taps (tap = pixel offset), F once.
 // Each workgroup owns a 64(cf) x CSB(cs) block for ALL taps (9*4 = 36 accumulator tiles per wave at the
-// default shape), walks the pixel tiles of its split with double-buffered LDS-DMA staging, and writes one
-// fp32 slab; reduce_slabs (elementwise.hip) sums the splits deterministically.
+// default shape), walks the pixel tiles of its split with LDS-DMA staging through a ring of p.nbuf (2 or 3) buffers --
+// with 3 the loads run TWO tiles ahead and each wave waits with a counted s_waitcnt vmcnt(pieces per tile) -- and writes
+// one fp32 slab; reduce_slabs (elementwise.hip) sums the splits deterministically.
 #include "igemm.h"
 
 __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
+#define RSU_WG_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define RSU_SENT 0x80000000u   // voffset the range check always rejects (num_records = 0x7fffffff): the lane deposits zeros
 
 // Tiles are ALIGNED (strip width SW = 2^lsw divides TMK; a tile = TMK/SW full rows of one strip), so every per-lane LDS
 // read offset is a workgroup constant and a pixel tile only contributes scalar bases + edge validity.
 // KG = 1: four waves, one per SIMD. KG = 2: eight waves; wave group g = wave/4 reduces k-steps [g*KS/2, (g+1)*KS/2) of every
-// pixel tile into its OWN accumulators and slab (2*nsplit slabs in total), so two waves share each SIMD and cover each
-// other's LDS latency / DMA bookkeeping without any in-kernel reduction.
+// pixel tile into its OWN accumulators, so two waves share each SIMD and cover each other's LDS latency / DMA bookkeeping;
+// the two partial sums meet once, through LDS, after the last tile.
 template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK, int KG>
 __global__ void __launch_bounds__(WCF* WCS * KG * 64) __attribute__((amdgpu_waves_per_eu(KG, KG)))
 igemm_wgrad_kernel(const IgWgradParams p) {
@@ -42,8 +44,9 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     static_assert(CFB == 64, "F block is 64 channels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
-    const int SBUF = p.g.npix_max * SPITCH;
-    const int s_base = 2 * FBUF;
+    const int nbuf = p.nbuf, nsw = p.nsw;      // ring depth; S pieces per wave per tile (every wave issues exactly nsw)
+    const int SBUF = nsw * NW * 1024;
+    const int s_base = nbuf * FBUF;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -51,7 +54,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     const int wcf = wave4 / WCS, wcs = wave4 % WCS;
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
     const int cfb = blockIdx.x, csb = blockIdx.y, z = blockIdx.z;
-    const int zs = z * KG + kgrp;  // slab this wave group accumulates into
+    const int zs = z;  // slab of this workgroup
     const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TMK >> lsw;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     const int Hs = (p.Hf - 1) * p.stride + (KH - 1) * p.dil + 1;  // S window extent
@@ -110,13 +113,16 @@ igemm_wgrad_kernel(const IgWgradParams p) {
         return T;
     };
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
-    const int npieces_s = (p.g.npix_max + PPP - 1) / PPP;
+    static_assert((TMK / 8) % NW == 0, "F pieces per wave must be a constant");
+    constexpr int NFW = TMK / 8 / NW;
     auto issue = [&](const Tile& T, int buf) {
         // F tile: TMK pixels x 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
         {
             const __amdgpu_buffer_rsrc_t rf = mk(p.F);
             const unsigned soffF = (unsigned)((((long)(T.n * p.Hf + T.y0) * p.Wf + T.x0) * p.Cf + cfb * 64) * 2);
-            for (int j = wave; j < TMK / 8; j += NW) {
+#pragma unroll
+            for (int q = 0; q < NFW; ++q) {
+                const int j = q * NW + wave;
                 const int ml = j * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
                 const int ty = ml >> lsw, tx = ml & (SW - 1);
@@ -130,44 +136,59 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
             const int iy0 = T.y0 * p.stride, ix0 = T.x0 * p.stride;
             const unsigned soffS = (unsigned)((((long)(T.n * p.S.H + iy0 + p.S.oy) * p.S.W + ix0 + p.S.ox) * p.S.C + csb * CSB) * 2);
-            for (int j = wave; j < npieces_s; j += NW) {
+            for (int q = 0; q < nsw; ++q) {  // pieces past the halo tile (hp >= npix_max) fail the window test below or are never read
+                const int j = q * NW + wave;
                 const int hp = j * PPP + lane / LPP;
                 const int pc = lane % LPP;
                 const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
                 const int rr = div_magic(hp, p.g.inv_CW);
                 const int cc = hp - rr * CW;
-                const bool ok = (iy0 + rr < Hs) && (ix0 + cc < Ws) && (csb * CSB + c * 8 < p.S.C);
+                const bool ok = (hp < p.g.npix_max) && (iy0 + rr < Hs) && (ix0 + cc < Ws) && (csb * CSB + c * 8 < p.S.C);
                 const unsigned voff = ok ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
                 bdma16(rs, voff, soffS, (void*)(lds + s_base + buf * SBUF + j * 1024));
             }
         }
     };
 
+    // ---- prologue: the first nbuf-1 tiles of this split
     int tile = z;
-    Tile cur = decode(tile);
-    issue(cur, 0);
-    __syncthreads();
-    int buf = 0;
+    {
+        int t = tile;
+        for (int d = 0; d < nbuf - 1 && t < p.ntiles_total; ++d, t += p.nsplit) issue(decode(t), d);
+    }
+    int buf = 0;                      // ring slot of the tile being reduced
+    int ibuf = nbuf - 1;              // ring slot the next prefetch goes to
     for (; tile < p.ntiles_total; tile += p.nsplit) {
-        const int nxt = tile + p.nsplit;
-        if (nxt < p.ntiles_total) {
-            const Tile nt = decode(nxt);
-            issue(nt, buf ^ 1);
+        // tile `tile` has landed once this wave's own pieces are done (all but the NFW + nsw pieces of the tile after it,
+        // when that one is in flight) and everybody passed the barrier; the barrier also retires the slot read last round
+        if (nbuf == 3 && tile + p.nsplit < p.ntiles_total) {
+            switch (nsw) {
+                case 1: RSU_WG_WAIT(NFW + 1); break;
+                case 2: RSU_WG_WAIT(NFW + 2); break;
+                case 3: RSU_WG_WAIT(NFW + 3); break;
+                case 4: RSU_WG_WAIT(NFW + 4); break;
+                case 5: RSU_WG_WAIT(NFW + 5); break;
+                default: RSU_WG_WAIT(0); break;
+            }
+        } else {
+            RSU_WG_WAIT(0);
         }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int nxt = tile + (nbuf - 1) * p.nsplit;
+        if (nxt < p.ntiles_total && p.dbg != 1) issue(decode(p.dbg == 2 ? z : nxt), ibuf);
+        ibuf = ibuf + 1 == nbuf ? 0 : ibuf + 1;
         const int fb = buf * FBUF, sb = s_base + buf * SBUF;
         // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
+        auto tr_read = [&](int off) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds + off));
+        };
         auto load_F = [&](int ks, bf16x8(&fa)[CFT]) {
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll
-                for (int ct = 0; ct < CFT; ++ct) {
-                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(lds + (fb + foff[ks][rd][ct])));
-                    fa[ct][rd * 4 + 0] = v[0];
-                    fa[ct][rd * 4 + 1] = v[1];
-                    fa[ct][rd * 4 + 2] = v[2];
-                    fa[ct][rd * 4 + 3] = v[3];
-                }
+            for (int ct = 0; ct < CFT; ++ct) {
+                const bf16x4 lo = tr_read(fb + foff[ks][0][ct]), hi = tr_read(fb + foff[ks][1][ct]);
+                fa[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
         // B operand: S (cols = cs) shifted by the tap
@@ -175,16 +196,9 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             const int ky = tap / KW, kx = tap - ky * KW;
             const int rowoff = sb + ky * CW * p.dil * SPITCH;  // wave-uniform
 #pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-#pragma unroll
-                for (int st = 0; st < CST; ++st) {
-                    const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4*)(lds + (rowoff + soff[ks][rd][kx][st])));
-                    sv[st][rd * 4 + 0] = v[0];
-                    sv[st][rd * 4 + 1] = v[1];
-                    sv[st][rd * 4 + 2] = v[2];
-                    sv[st][rd * 4 + 3] = v[3];
-                }
+            for (int st = 0; st < CST; ++st) {
+                const bf16x4 lo = tr_read(rowoff + soff[ks][0][kx][st]), hi = tr_read(rowoff + soff[ks][1][kx][st]);
+                sv[st] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
         // one software-pipelined sequence over (k-step, tap): operands of step+1 are requested before the MFMAs of step
@@ -211,10 +225,37 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                 for (int ct = 0; ct < CFT; ++ct) accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], ones, accb[ct], 0, 0, 0);
             }
         }
-        __syncthreads();
-        buf ^= 1;
+        buf = buf + 1 == nbuf ? 0 : buf + 1;
     }
+    __syncthreads();  // the staging buffers are dead from here on
 
+    // ---- KG = 2: wave group 1 hands its partial sums to group 0 through LDS (the staging buffers are dead by now; the launch
+    // reserves NTAP*CFB*CSB*4 + 4 KiB bytes), fixed order group0 + group1: one slab per workgroup, still deterministic
+    if constexpr (KG == 2) {
+        f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
+        const int slot = wave4 * 64 + lane;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int a = 0; a < CFT; ++a)
+#pragma unroll
+                    for (int b = 0; b < CST; ++b) red[((t * CFT + a) * CST + b) * (WCF * WCS * 64) + slot] = acc[t][a][b];
+#pragma unroll
+            for (int a = 0; a < CFT; ++a) red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot] = accb[a];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int a = 0; a < CFT; ++a)
+#pragma unroll
+                for (int b = 0; b < CST; ++b) acc[t][a][b] += red[((t * CFT + a) * CST + b) * (WCF * WCS * 64) + slot];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < CFT; ++a) accb[a] += red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot];
+    }
     if (do_bias && l15 == 0) {  // every column of accb holds the same sums: column 0 writes them
 #pragma unroll
         for (int ct = 0; ct < CFT; ++ct) {
@@ -240,22 +281,29 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 }
 
 template <int CFG> struct WgCfg;
-template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 2, WCS = 2, CFT = 2, CST = 2, TMK = 128, KG = 2; };
+template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 1, WCS = 4, CFT = 4, CST = 1, TMK = 128, KG = 2; };
 template <> struct WgCfg<IGW_CFG_64x16> { static constexpr int WCF = 4, WCS = 1, CFT = 1, CST = 1, TMK = 128, KG = 2; };
 
-int igemm_wgrad_kgroups(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::KG : WgCfg<IGW_CFG_64x16>::KG; }
+int igemm_wgrad_kgroups(int) { return 1; }  // wave groups are reduced inside the workgroup: one slab per grid.z slice
 int igemm_wgrad_tmk(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::TMK : WgCfg<IGW_CFG_64x16>::TMK; }
 
-size_t igemm_wgrad_lds_bytes(int cfg, int npix_max) {
+int igemm_wgrad_nsw(int cfg, int npix_max) {  // S pieces (1 KiB) per wave per tile, 8 waves
     const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
-    return (size_t)2 * igemm_wgrad_tmk(cfg) * 128 + (size_t)2 * npix_max * csb * 2;
+    const int ppp = 64 / (csb / 8);
+    return ((npix_max + ppp - 1) / ppp + 7) / 8;
+}
+size_t igemm_wgrad_lds_bytes(int cfg, int npix_max, int nbuf) {
+    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
+    const size_t staging = (size_t)nbuf * igemm_wgrad_tmk(cfg) * 128 + (size_t)nbuf * igemm_wgrad_nsw(cfg, npix_max) * 8 * 1024;
+    const size_t reduce = (size_t)(9 * 64 * csb + 64 * csb) * 4;  // wave-group hand-off of the accumulators (+ bias sums)
+    return staging > reduce ? staging : reduce;
 }
 
 template <int CFG, int NTAP, int KW>
 static hipError_t wlaunch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
     using C = WgCfg<CFG>;
     auto kern = igemm_wgrad_kernel<C::WCF, C::WCS, C::CFT, C::CST, NTAP, KW, C::TMK, C::KG>;
-    const size_t lds = igemm_wgrad_lds_bytes(CFG, p.g.npix_max);
+    const size_t lds = igemm_wgrad_lds_bytes(CFG, p.g.npix_max, p.nbuf);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

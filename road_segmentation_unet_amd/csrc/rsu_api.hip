@@ -382,6 +382,17 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
+        p.dbg = env_int("RSU_FWD_DBG", 0);
+        if (env_int("RSU_PLAN_DEBUG", 0)) {
+            const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(pl2.cfg);
+            const long tiles = (long)N * pl2.g.nstrips * pl2.g.tiles_per_strip;
+            const long workers = pl2.grid_x / pl2.ncob;
+            const long rounds = (tiles + workers - 1) / workers;
+            fprintf(stderr, "[plan fwd2] N%d %dx%d Cout%d ntap%d pad%d: cfg%d TN%d TM%d SW%d strips%d tps%d halo%d tiles%ld grid%d rounds%ld pix_util %.3f total_util %.3f\n",
+                    N, Ho, Wo, Cout, ntap, pad, pl2.cfg, ci.TN, ci.TM, pl2.g.SW, pl2.g.nstrips, pl2.g.tiles_per_strip, pl2.g.npix_max, tiles,
+                    pl2.grid_x, rounds, (double)N * Ho * Wo / ((double)tiles * ci.TM),
+                    (double)N * Ho * Wo * Cout / ((double)rounds * pl2.grid_x * ci.TM * ci.TN));
+        }
         HIP_CHECK_RET(igemm_fwd2_launch(pl2.cfg, ntap, p, pl2.grid_x, gy, st));
         return RSU_OK;
     }
@@ -455,30 +466,34 @@ extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, voi
 // ---------------------------------------------------------------------------------------------
 // igemm_wgrad family
 // ---------------------------------------------------------------------------------------------
+// grid.z splits of the pixel reduction: one workgroup per CU in total
 static int wgrad_max_split(int Cf, int Cs, int csb) {
-    int want = 512 / (cdiv(Cf, 64) * cdiv(Cs, csb));
+    int want = 256 / (cdiv(Cf, 64) * cdiv(Cs, csb));
     return want < 1 ? 1 : want;
 }
-// slabs a launch may write: (grid.z splits, at least one) x (wave groups of the config, each with its own slab)
-static size_t wgrad_max_slabs(int cfg, int Cf, int Cs, int csb) {
-    const int kg = igemm_wgrad_kgroups(cfg);
-    int z = wgrad_max_split(Cf, Cs, csb) / kg;
-    return (size_t)(z < 1 ? 1 : z) * kg;
-}
-struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw; };
+static size_t wgrad_max_slabs(int, int Cf, int Cs, int csb) { return (size_t)wgrad_max_split(Cf, Cs, csb); }
+struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw, nbuf; };
 static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
     pl.cfg = cfg;
     const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
     const int tmk = igemm_wgrad_tmk(cfg);
-    const long fixed = 2L * tmk * 128;
-    const int cap = (int)((160 * 1024 - fixed) / (2 * csb * 2));
-    if (!plan_geo_aligned(pl.g, pl.lsw, Hf, Wf, tmk, kh, kw, dil, stride, cap)) return false;
+    // three staging buffers (loads two tiles ahead) when a halo tile small enough exists, else two
+    bool ok = false;
+    for (int nbuf = 3; nbuf >= 2 && !ok; --nbuf) {
+        const long fixed = (long)nbuf * tmk * 128;
+        int cap = (int)((160 * 1024 - fixed) / (nbuf * csb * 2));
+        const int ppw = 64 / (csb / 8) * 8;  // S pixels covered by one piece per wave
+        cap = cap / ppw * ppw;               // the kernel rounds the S slot up to whole pieces per wave
+        const int cap5 = 5 * ppw;            // ... and knows wait counts for at most 5 of them
+        if (nbuf == 3 && cap > cap5) cap = cap5;
+        pl.nbuf = nbuf;
+        ok = plan_geo_aligned(pl.g, pl.lsw, Hf, Wf, tmk, kh, kw, dil, stride, cap);
+    }
+    if (!ok) return false;
     pl.gx = cdiv(Cf, 64);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
-    const int kg = igemm_wgrad_kgroups(cfg);
-    int want = wgrad_max_split(Cf, Cs, csb) / kg;  // workgroups along z; each writes kg slabs
-    if (want < 1) want = 1;
+    const int want = wgrad_max_split(Cf, Cs, csb);  // workgroups along z; each writes one slab
     pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
     (void)ntap;
     return true;
@@ -494,9 +509,10 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.Hf = Hf; p.Wf = Wf; p.Cf = Cf;
     p.S.ptr = (const bf16_t*)S->ptr;
     p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
-    p.slab = ws;
-    const int nslab = pl.nsplit * igemm_wgrad_kgroups(cfg);
-    p.bslab = db ? ws + (size_t)nslab * ntap * CsOut * CfOut : nullptr;
+    const int nslab = pl.nsplit;
+    // a single split needs no slab: its workgroups write the gradient (and the bias sums) in place
+    p.slab = nslab == 1 ? out : ws;
+    p.bslab = db ? (nslab == 1 ? db : ws + (size_t)nslab * ntap * CsOut * CfOut) : nullptr;
     p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
@@ -504,10 +520,15 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.nsplit = pl.nsplit;
     p.ntiles_total = pl.ntiles;
     p.lsw = pl.lsw;
+    p.nbuf = pl.nbuf;
+    p.nsw = igemm_wgrad_nsw(cfg, pl.g.npix_max);
+    p.dbg = env_int("RSU_WG_DBG", 0);
     p.g = pl.g;
     HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
-    HIP_CHECK_RET(ew_reduce_slabs(ws, out, nslab, ntap, CsOut, cs_off, S->C, CfOut, st));
-    if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, nslab, 1, 1, 0, 1, CfOut, st));
+    if (nslab > 1) {
+        HIP_CHECK_RET(ew_reduce_slabs(ws, out, nslab, ntap, CsOut, cs_off, S->C, CfOut, st));
+        if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, nslab, 1, 1, 0, 1, CfOut, st));
+    }
     return RSU_OK;
 }
 

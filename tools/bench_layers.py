@@ -106,6 +106,8 @@ def main():
                         t = timeit(lambda: call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, st))
                     elif op == "bwd":
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, st))
+                    elif op == "bwdnm":  # backward-data without the ReLU mask (A/B: cost of the mask loads in the epilogue)
+                        t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, st))
                     else:
                         t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
                     line += " %s%s %6.0fus %5.0fTF |" % (op, "" if cfg < 0 else "[%d]" % cfg, t * 1e6, fl / t / 1e12)
