@@ -481,32 +481,36 @@ __global__ void __launch_bounds__(256) k_pack_many(const PackJob* __restrict__ j
     long hi = b0 + PACK_EPB;
     if (hi > total) hi = total;
     PackParams pp = jb.pp;
-    // restrict the generic loop to this block's slice by faking the total through the stride trick: walk the slice directly
-    for (long e = b0 + threadIdx.x; e < hi; e += 256) {
-        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
-        long r = e >> 9;
-        const int T = (int)(r % pp.ntiles);
-        r /= pp.ntiles;
-        const int tap = (int)(r % pp.ntap), chunk = (int)(r / pp.ntap);
+    // one thread per 16-byte group (lane, j = 0..7): 32-bit index math once per group, eight strided reads, one 16-byte store
+    const unsigned g0 = (unsigned)(b0 >> 3), g1 = (unsigned)((hi + 7) >> 3);
+    for (unsigned gidx = g0 + threadIdx.x; gidx < g1; gidx += 256) {
+        const int lane = (int)(gidx & 63);
+        unsigned r = gidx >> 6;
+        const int T = (int)(r % (unsigned)pp.ntiles);
+        r /= (unsigned)pp.ntiles;
+        const int tap = (int)(r % (unsigned)pp.ntap), chunk = (int)(r / (unsigned)pp.ntap);
         const int rho = lane & 15;
         const int row = 32 * (T >> 1) + 8 * (rho >> 2) + 4 * (T & 1) + (rho & 3);
-        const int k = chunk * 32 + 8 * (lane >> 4) + j;
-        int kreal = -1, base_pad = 0, base_real = 0;
+        const int k0 = chunk * 32 + 8 * (lane >> 4);  // the 8 k of a group lie in one (32-padded) segment
+        int kreal0 = 0, nvalid = 0, base_pad = 0, base_real = 0;
         for (int sgi = 0; sgi < pp.nseg; ++sgi) {
             const int cpad = (pp.seg_c[sgi] + 31) & ~31;
-            if (k >= base_pad && k < base_pad + cpad) {
-                const int c = k - base_pad;
-                if (c < pp.seg_c[sgi]) kreal = base_real + c;
+            if (k0 >= base_pad && k0 < base_pad + cpad) {
+                const int c = k0 - base_pad;
+                kreal0 = base_real + c;
+                nvalid = pp.seg_c[sgi] - c;
             }
             base_pad += cpad;
             base_real += pp.seg_c[sgi];
         }
-        float v = 0.f;
-        if (kreal >= 0 && row < pp.rows) {
-            const int tsrc = pp.flip ? (pp.ntap - 1 - tap) : tap;
-            v = jb.src[(long)tsrc * pp.s_tap + (long)row * pp.s_row + (long)kreal * pp.s_k];
-        }
-        jb.dst[e] = f2bf(v);
+        if (row >= pp.rows) nvalid = 0;
+        const int tsrc = pp.flip ? (pp.ntap - 1 - tap) : tap;
+        const float* sp = jb.src + (long)tsrc * pp.s_tap + (long)row * pp.s_row + (long)kreal0 * pp.s_k;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = j < nvalid ? sp[(long)j * pp.s_k] : 0.f;
+        const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(jb.dst + (long)gidx * 8) = o;
     }
 }
 

@@ -18,10 +18,12 @@
 
 #define RSU_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int SPC, int WPS, int NA>
+template <int SPC, int WPS, int NA, int DA>
 __device__ __forceinline__ constexpr int vm_allowed(int j) {
-    // loads that may still be in flight when stage position j starts (issue order: see the kernel body)
-    return SPC == 1 ? WPS : (j == 0 ? WPS : WPS + NA);
+    // loads that may still be in flight when stage position j starts (issue order: see the kernel body).
+    // SPC == 1 (one stage per chunk, halo DA chunks ahead, weights DA+1 stages ahead): everything issued after the halo of
+    // this stage = the weights of that same stage position plus the complete issues of the DA-1 stages since
+    return SPC == 1 ? WPS + (DA - 1) * (NA + WPS) : (j == 0 ? WPS : WPS + NA);
 }
 
 // buffer -> LDS copy of 16 bytes per lane: out-of-range lanes (voffset + soffset >= num_records) deposit ZEROS, which is
@@ -42,7 +44,10 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
 // scalar bases (soffset) and edge validity.
 // NW = WCO*WPX waves: 4 (one per SIMD, big wave tiles) or 8 (two per SIMD: one wave's address arithmetic, waits and
 // LDS latency overlap its partner's MFMAs)
-template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA>
+// NAB = halo ring slots (prefetch distance NAB-1 chunks), NAB+1 weight slots (distance NAB stages). 2 for the 3x3 kernels
+// (a chunk is three stages long, one chunk ahead is plenty); deeper for the one-stage-per-chunk kernels (1x1 / transposed
+// conv), whose stages are too short to cover a load's latency
+template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA, int NAB>
 __global__ void __launch_bounds__(WCO* WPX * 64) __attribute__((amdgpu_waves_per_eu(WCO* WPX / 4, WCO* WPX / 4)))
 igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int NW = WCO * WPX;
@@ -51,15 +56,17 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int WT = TN / 16;
     constexpr int SPC = NTAP / TPS;
     constexpr int WBUF = TPS * WT * 1024;
-    constexpr int NWB = 3;                     // weight ring slots (prefetch distance 2)
+    constexpr int NWB = NAB + 1;               // weight ring slots
+    constexpr int DA = NAB - 1, DW = NAB;      // prefetch distances: halo (chunks), weights (stages)
     constexpr int WPS = (TPS * WT + NW - 1) / NW;  // weight DMA instructions per wave per stage (padded to a constant)
     constexpr int NST = (CT / 2) * PT;         // epilogue buffer stores per wave per tile (always issued)
     static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && SPC <= 3, "bad config");
+    static_assert(SPC == 1 || NAB == 2, "deep rings only for one-stage-per-chunk kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
     const int ABUF = p.g.npix_max * 64;
     const int a_base = NWB * WBUF;
-    const int dummy_base = a_base + 2 * ABUF;  // 1 KiB scratch slot for padding loads
+    const int dummy_base = a_base + NAB * ABUF;  // 1 KiB scratch slot for padding loads
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -158,8 +165,9 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             amask |= ok ? (1u << q) : 0u;
         }
     };
-    int a_cl = 0;  // chunk (inside its tile) of the next halo to prefetch
-    auto issue_a = [&](int gc, const Tile& T) {
+    int a_cl = 0;    // chunk (inside its tile) of the next halo to prefetch
+    int ia_slot = 0; // its ring slot
+    auto issue_a = [&](const Tile& T) {
         int si = 0, cl = a_cl;
         a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
         if (cl >= p.nchunk[0]) {
@@ -181,7 +189,8 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         const __amdgpu_buffer_rsrc_t rs = mk(sptr - ((long)p.pad * sW + p.pad) * sC);
         // scalar byte offset of the (padded) halo origin in this source, plus the channel chunk
         const unsigned soff = (unsigned)((((long)(T.n * sH + T.y0 * p.stride + soy) * sW + (T.x0 * p.stride + sox)) * sC + c0) * 2);
-        const int dst = a_base + (gc & 1) * ABUF;
+        const int dst = a_base + ia_slot * ABUF;
+        ia_slot = ia_slot == NAB - 1 ? 0 : ia_slot + 1;
         const int crem = sC - c0;  // channels left in this source (>= 32 except in a partial last chunk)
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
@@ -214,16 +223,29 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         // scalar byte offset of the tile's first output pixel (+ this wave's first channel)
         const unsigned sbase = (unsigned)((((long)(T.n * p.oH + T.y0 * p.ostride + ooffy) * p.oW + T.x0 * p.ostride + ooffx) * p.outC +
                                            cob * TN + wco * (CT / 2) * 32) * 2);
+        // NST stores in batches of four: the mask / accumulate loads of a batch are requested together (one memory latency per
+        // batch instead of one per store); larger batches would need more than the 16-32 VGPRs that are free here
+        constexpr int EB = 4;
+        static_assert(NST % EB == 0, "epilogue batches");
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int ml = (wpx * PT + pt) * 16 + l15;
-            const int ty = ml >> lsw, tx = ml & (SW - 1);
-            const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
-            const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
+        for (int b0 = 0; b0 < NST; b0 += EB) {
+            unsigned voffs[EB];
+            u32x4 mk4[EB], ob4[EB];
 #pragma unroll
-            for (int pp = 0; pp < CT / 2; ++pp) {
+            for (int e = 0; e < EB; ++e) {
+                const int pt = (b0 + e) / (CT / 2), pp = (b0 + e) % (CT / 2);
+                const int ml = (wpx * PT + pt) * 16 + l15;
+                const int ty = ml >> lsw, tx = ml & (SW - 1);
+                const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
+                const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
                 const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
-                const unsigned voff = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
+                voffs[e] = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
+                if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
+                if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int pt = (b0 + e) / (CT / 2), pp = (b0 + e) % (CT / 2);
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -231,19 +253,17 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                     v[4 + i] = acc[2 * pp + 1][pt][i];
                 }
                 if (p.mask_src) {
-                    const u32x4 mk4 = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voff, sbase, 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (!(bf_lo(mk4[i]) > 0.f)) v[2 * i] = 0.f;
-                        if (!(bf_hi(mk4[i]) > 0.f)) v[2 * i + 1] = 0.f;
+                        if (!(bf_lo(mk4[e][i]) > 0.f)) v[2 * i] = 0.f;
+                        if (!(bf_hi(mk4[e][i]) > 0.f)) v[2 * i + 1] = 0.f;
                     }
                 }
                 if (p.accumulate) {
-                    const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voff, sbase, 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        v[2 * i] += bf_lo(o[i]);
-                        v[2 * i + 1] += bf_hi(o[i]);
+                        v[2 * i] += bf_lo(ob4[e][i]);
+                        v[2 * i + 1] += bf_hi(ob4[e][i]);
                     }
                 }
                 unsigned r0 = pack_bf2(v[0], v[1]), r1 = pack_bf2(v[2], v[3]), r2 = pack_bf2(v[4], v[5]), r3 = pack_bf2(v[6], v[7]);
@@ -254,9 +274,9 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                     r3 = relu_pk_bf16(r3);
                 }
                 const u32x4 r = {r0, r1, r2, r3};
-                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voff, sbase, 0);
-                __builtin_amdgcn_sched_barrier(0);  // keep the 16 iterations apart: hoisting all their loads costs 128 VGPRs
+                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voffs[e], sbase, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
         }
     };
 
@@ -264,12 +284,32 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     Tile ptile = decode(0);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
     prep_a(ptile);
-    issue_a(0, ptile);
-    issue_w();
-    if (GC * SPC > 1) issue_w();
+    bool a_started = false;
+    auto issue_a_next = [&]() {  // halo of the next chunk of the stream (moves on to the next tile after a tile's last chunk)
+        if (a_cl == 0 && a_started) {
+            ++pk;
+            ptile = decode(pk);
+            prep_a(ptile);
+        }
+        a_started = true;
+        issue_a(ptile);
+    };
+    if constexpr (SPC == 1) {
+        // the issues of the DW stages "before" stage 0, in steady-state order (halo of stage k+DA, then weights of stage k+DW)
+#pragma unroll
+        for (int k = -DW; k < 0; ++k) {
+            if (k + DA >= 0 && k + DA < GC) issue_a_next();
+            if (k + DW < GC) issue_w();
+        }
+    } else {
+        issue_a_next();
+        issue_w();
+        if (GC * SPC > 1) issue_w();
+    }
 
     int gc = 0;      // stream chunk counter
     int c_slot = 0;  // weight ring slot of the stage being computed
+    int ca_slot = 0; // halo ring slot of the chunk being computed
     for (int ck = 0; ck < my_tiles; ++ck) {
         const Tile ctile = decode(ck);
         // accumulators live for exactly one tile (no loop-carried copies across the epilogue); they start at the bias
@@ -283,13 +323,13 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
             // every wave may rely on the constant per-stage counts only while the two chunks ahead exist
-            const bool steady = gc + 2 < GC;
-            // first chunk after an epilogue: its 16-byte stores sit in the VMEM queue behind the loads stage 0/1 wait for
-            const bool after_epi = (c == 0) && gc > 0;
+            const bool steady = (gc + DW < GC) && (SPC > 1 || nchunks >= DA);
+            // first stages after an epilogue: its 16-byte stores sit in the VMEM queue behind the loads these stages wait for
+            const bool after_epi = SPC == 1 ? (c < DA && ck > 0) : ((c == 0) && gc > 0);
             auto stage = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const int st = gc * SPC + j;
-                constexpr int ALLOWED = vm_allowed<SPC, WPS, NA>(j);
+                constexpr int ALLOWED = vm_allowed<SPC, WPS, NA, DA>(j);
                 if (!steady) {
                     RSU_WAIT_VMCNT(0);
                 } else if (after_epi && j < 2) {
@@ -302,7 +342,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 asm volatile("" ::: "memory");
                 // ---- compute stage st from weight slot st%NWB and halo slot gc&1
                 const int wb = c_slot * WBUF;
-                const int ab = a_base + (gc & 1) * ABUF;
+                const int ab = a_base + ca_slot * ABUF;
                 bf16x8 fa[2][CT], fb[2][PT];
                 auto load_tap = [&](int tl, bf16x8(&a)[CT], bf16x8(&b)[PT]) {
                     const int tap = j * TPS + tl;
@@ -318,25 +358,11 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 auto prefetch = [&]() {
                 // prefetch: (SPC == 1: halo first, then weights; otherwise weights, then halo at position 0)
                     if (SPC == 1) {
-                        if (gc + 1 < GC && !(p.dbg & 2)) {
-                            if (c + 1 == nchunks) {
-                                ++pk;
-                                ptile = decode(pk);
-                                prep_a(ptile);
-                            }
-                            issue_a(gc + 1, ptile);
-                        }
-                        if (st + 2 < GC * SPC && !(p.dbg & 1)) issue_w();
+                        if (gc + DA < GC && !(p.dbg & 2)) issue_a_next();
+                        if (st + DW < GC * SPC && !(p.dbg & 1)) issue_w();
                     } else {
                         if (st + 2 < GC * SPC && !(p.dbg & 1)) issue_w();
-                        if (j == 0 && gc + 1 < GC && !(p.dbg & 2)) {
-                            if (c + 1 == nchunks) {
-                                ++pk;
-                                ptile = decode(pk);
-                                prep_a(ptile);
-                            }
-                            issue_a(gc + 1, ptile);
-                        }
+                        if (j == 0 && gc + 1 < GC && !(p.dbg & 2)) issue_a_next();
                     }
                 };
                 load_tap(0, fa[0], fb[0]);
@@ -370,6 +396,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 stage(std::integral_constant<int, 2>{});
                 c_slot = c_slot == NWB - 1 ? 0 : c_slot + 1;
             }
+            ca_slot = ca_slot == NAB - 1 ? 0 : ca_slot + 1;
         }
         epilogue(ctile, acc);
     }
@@ -386,6 +413,7 @@ template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> { static constexpr int WCO = 2, 
 template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8, NA = 10; };
 
 static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
+static constexpr int nab_for(int TN, int ntap) { return ntap / tps2_for(TN, ntap) == 1 ? 4 : 2; }
 
 IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
     switch (cfg) {
@@ -416,8 +444,8 @@ int igemm_fwd2_max_pieces(int cfg) {
 }
 size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max) {
     const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
-    const int tps = tps2_for(ci.TN, ntap);
-    return (size_t)3 * tps * (ci.TN / 16) * 1024 + (size_t)2 * npix_max * 64 + 1024 + 512;
+    const int tps = tps2_for(ci.TN, ntap), nab = nab_for(ci.TN, ntap);
+    return (size_t)(nab + 1) * tps * (ci.TN / 16) * 1024 + (size_t)nab * npix_max * 64 + 1024 + 512;
 }
 
 template <int CFG, int NTAP, int KW>
@@ -425,7 +453,7 @@ static hipError_t launch2_one(const IgFwdParams& p, int gx, int gy, hipStream_t 
     using C = Fwd2Cfg<CFG>;
     constexpr int TN = C::WCO * C::CT * 16;
     constexpr int TPS = tps2_for(TN, NTAP);
-    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::NA>;
+    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::NA, nab_for(TN, NTAP)>;
     const size_t lds = igemm_fwd2_lds_bytes(CFG, NTAP, p.g.npix_max);
     static size_t lds_set = 0;
     if (lds > lds_set) {

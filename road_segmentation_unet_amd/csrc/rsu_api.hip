@@ -301,7 +301,8 @@ static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int
 
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
 struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
-static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int force_cfg) {
+static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
+                      int force_cfg) {
     double best_cost = 1e300;
     bool have = false;
     for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
@@ -311,7 +312,8 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         if (Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
         if (Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
         const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
-        int cap = (int)((160 * 1024 - fixed) / 128);
+        const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, ntap, 1) - fixed;  // 64 bytes x halo ring slots
+        int cap = (int)((160 * 1024 - fixed) / per_pix);
         const int cap2 = igemm_fwd2_max_pieces(cfg) * 16;
         if (cap2 < cap) cap = cap2;
         TileGeo g;
@@ -319,12 +321,16 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
         const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
-        long workers = 256 / ncob;
+        long workers = 256 / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
         if (workers < 1) workers = 1;
         if (workers > ntile_m) workers = ntile_m;
         const long rounds = (ntile_m + workers - 1) / workers;
-        // per tile: MFMA work ~ TM*TN per (chunk, tap) + a fixed epilogue/bubble term
-        const double cost = (double)rounds * ((double)ci.TM * ci.TN + 4096.0);
+        // per tile: MFMA work ~ TM*TN per (chunk, tap) + a fixed epilogue/bubble term, which weighs more the shorter the
+        // reduction (ktot = taps x channels) is
+        double ovh = 4096.0 * 1152.0 / (double)(ktot > 0 ? ktot : 1152);
+        if (ovh < 4096.0) ovh = 4096.0;
+        if (ovh > 65536.0) ovh = 65536.0;
+        const double cost = (double)rounds * ((double)ci.TM * ci.TN + ovh);
         if (cost < best_cost) {
             best_cost = cost;
             best.cfg = cfg;
@@ -348,7 +354,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
         if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) gen2 = false;
     FwdPlan pl;
     Fwd2Plan pl2;
-    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD2_CFG", -1));
+    int ktot = 0;
+    for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * ntap;
+    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, env_int("RSU_FWD2_CFG", -1));
     if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
