@@ -74,10 +74,12 @@ struct IgWgradParams {
     int dbg;            // developer A/B switch (RSU_WG_DBG): 1 = skip the staging loads of all but the first tile (timing only)
     TileGeo g;          // TM of this geometry = pixels per reduction tile
 };
-enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_NCFG = 2 };
+enum { IGW_CFG_64x64 = 0, IGW_CFG_64x16 = 1, IGW_CFG_128x64 = 2, IGW_NCFG = 3 };
 size_t igemm_wgrad_lds_bytes(int cfg, int npix_max, int nbuf);
 int igemm_wgrad_nsw(int cfg, int npix_max);
 int igemm_wgrad_tmk(int cfg);
+int igemm_wgrad_cfb(int cfg);  // F channels per workgroup (grid.x block)
+int igemm_wgrad_csb(int cfg);  // S channels per workgroup (grid.y block)
 int igemm_wgrad_kgroups(int cfg);  // slabs written per grid.z slice
 hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,
                               hipStream_t st);

@@ -28,20 +28,22 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 // pixel tile into its OWN accumulators, so two waves share each SIMD and cover each other's LDS latency / DMA bookkeeping;
 // the two partial sums meet once, through LDS, after the last tile.
 template <int WCF, int WCS, int CFT, int CST, int NTAP, int KW, int TMK, int KG>
-__global__ void __launch_bounds__(WCF* WCS * KG * 64) __attribute__((amdgpu_waves_per_eu(KG, KG)))
+__global__ void __launch_bounds__(WCF* WCS * KG * 64) __attribute__((amdgpu_waves_per_eu(WCF* WCS* KG / 4, WCF* WCS* KG / 4)))
 igemm_wgrad_kernel(const IgWgradParams p) {
     constexpr int NW = WCF * WCS * KG;
     constexpr int KS = TMK / 32;          // 32-pixel MFMA steps per tile
     constexpr int KSG = KS / KG;          // ... per wave group
     static_assert(KS % KG == 0, "k-steps must split evenly over the wave groups");
-    constexpr int CFB = WCF * CFT * 16;  // must be 64
+    constexpr int CFB = WCF * CFT * 16;  // 64 or 128 (staged as CFB/64 planes of 64 channels)
+    constexpr int NPL = CFB / 64;
     constexpr int CSB = WCS * CST * 16;  // 64 or 16
     constexpr int KH = NTAP / KW;
     constexpr int SPITCH = CSB * 2;      // bytes per S pixel in LDS
     constexpr int LPP = CSB / 8;         // lanes (16-B pieces) per S pixel
     constexpr int PPP = 64 / LPP;        // S pixels per DMA piece
-    constexpr int FBUF = TMK * 128;
-    static_assert(CFB == 64, "F block is 64 channels");
+    constexpr int FPL = TMK * 128;       // bytes of one F plane
+    constexpr int FBUF = NPL * FPL;
+    static_assert(CFB % 64 == 0, "F block is a multiple of 64 channels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
     const int nbuf = p.nbuf, nsw = p.nsw;      // ring depth; S pieces per wave per tile (every wave issues exactly nsw)
@@ -73,34 +75,41 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     f32x4 accb[CFT];
 #pragma unroll
     for (int a = 0; a < CFT; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
-    // per-lane byte offsets of the transposed LDS reads (workgroup constants)
-    int foff[KSG][2][CFT];       // F tile: [k-step of this group][read][cf tile]
-    int soff[KSG][2][KW][CST];   // S halo tile: [k-step][read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
+    // per-lane byte offsets of the transposed LDS reads (workgroup constants) for the lane's pixel INSIDE a 32-pixel k-step;
+    // the k-step itself adds a compile-time constant to the F offset (32 pixels x 128 bytes) and a scalar to the S offset
+    // (whole rows, or half a row when SW = 64): both are multiples of 8 pixels, so the swizzle terms do not change
+    int f0[2];              // F tile: [read], cf tile 0 of this wave; tile ct is the same address with bits 5-6 XOR ct (the swizzle)
+    int soff[2][KW][CST];   // S halo tile: [read][kx][cs tile]; ky adds whole rows (CW % 8 == 0 keeps the swizzle)
 #pragma unroll
-    for (int ks = 0; ks < KSG; ++ks)
+    for (int rd = 0; rd < 2; ++rd) {
+        const int ml = rd * 16 + 4 * g4 + q4;
+        {
+            // channel of cf tile ct: ch = (wcf*CFT + ct)*16 + 4*p4; its 32-byte block inside the 128-byte pixel is
+            // ((ch>>4)&3) ^ ((ml>>1)&3). CFT = 4: wcf*CFT is a multiple of 4, so block(ct) = ct ^ m  ->  address(ct) = address(0) ^ (ct<<5).
+            // CFT < 4 keeps the general form (the XOR below then needs (wcf*CFT)&3 folded in, which address(0) already has)
+            const int ch = (wcf * CFT) * 16 + 4 * p4;
+            const int chl = ch & 63;
+            f0[rd] = (ch >> 6) * FPL + ml * 128 + ((((chl >> 4) ^ ((ml >> 1) & 3))) << 5) + (chl & 15) * 2;
+        }
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        const int hp0 = ty * p.stride * CW + tx * p.stride;
 #pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int ml = (kgrp * KSG + ks) * 32 + rd * 16 + 4 * g4 + q4;
+        for (int kx = 0; kx < KW; ++kx) {
+            const int hp = hp0 + kx * p.dil;
 #pragma unroll
-            for (int ct = 0; ct < CFT; ++ct) {
-                const int ch = (wcf * CFT + ct) * 16 + 4 * p4;
-                foff[ks][rd][ct] = ml * 128 + ((((ch >> 4) ^ ((ml >> 1) & 3))) << 5) + (ch & 15) * 2;
-            }
-            const int ty = ml >> lsw, tx = ml & (SW - 1);
-            const int hp0 = ty * p.stride * CW + tx * p.stride;
-#pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-                const int hp = hp0 + kx * p.dil;
-#pragma unroll
-                for (int st = 0; st < CST; ++st) {
-                    const int ch = (wcs * CST + st) * 16 + 4 * p4;
-                    soff[ks][rd][kx][st] = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
-                                                      : (hp * SPITCH + ch * 2);
-                }
+            for (int st = 0; st < CST; ++st) {
+                const int ch = (wcs * CST + st) * 16 + 4 * p4;
+                soff[rd][kx][st] = (LPP == 8) ? (hp * 128 + ((((ch >> 4) ^ ((hp >> 1) & 3))) << 5) + (ch & 15) * 2)
+                                              : (hp * SPITCH + ch * 2);
             }
         }
+    }
+    // S byte offset of k-step k (of the whole tile): scalar
+    auto sdelta = [&](int k) {
+        const int m0 = k * 32;
+        return (((m0 >> lsw) * CW + (m0 & (SW - 1))) * p.stride) * SPITCH;
+    };
 
     struct Tile { int n, x0, y0; };
     auto decode = [&](int tile) {
@@ -113,21 +122,26 @@ igemm_wgrad_kernel(const IgWgradParams p) {
         return T;
     };
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
-    static_assert((TMK / 8) % NW == 0, "F pieces per wave must be a constant");
-    constexpr int NFW = TMK / 8 / NW;
+    static_assert((NPL * TMK / 8) % NW == 0, "F pieces per wave must be a constant");
+    constexpr int NFW = NPL * TMK / 8 / NW;
+    // `ln` = lane id made opaque per call: keeps the compiler from hoisting the per-piece address arithmetic out of the tile
+    // loop (where it would sit in ~25 spilled VGPRs and come back through scratch loads + vmcnt(0) every tile)
     auto issue = [&](const Tile& T, int buf) {
-        // F tile: TMK pixels x 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // F tile: TMK pixels x CFB channels as planes of 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
         {
             const __amdgpu_buffer_rsrc_t rf = mk(p.F);
-            const unsigned soffF = (unsigned)((((long)(T.n * p.Hf + T.y0) * p.Wf + T.x0) * p.Cf + cfb * 64) * 2);
+            const unsigned soffF = (unsigned)((((long)(T.n * p.Hf + T.y0) * p.Wf + T.x0) * p.Cf + cfb * CFB) * 2);
 #pragma unroll
             for (int q = 0; q < NFW; ++q) {
                 const int j = q * NW + wave;
-                const int ml = j * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
+                const int pl = j / (TMK / 8), jj = j - pl * (TMK / 8);
+                const int ml = jj * 8 + (ln >> 3);
+                const int c = (ln & 7) ^ (((ml >> 1) & 3) << 1);
                 const int ty = ml >> lsw, tx = ml & (SW - 1);
-                const bool ok = (T.y0 + ty < p.Hf) && (T.x0 + tx < p.Wf) && (cfb * 64 + c * 8 < p.Cf);
-                const unsigned voff = ok ? (unsigned)(((ty * p.Wf + tx) * p.Cf + c * 8) * 2) : RSU_SENT;
+                const bool ok = (T.y0 + ty < p.Hf) && (T.x0 + tx < p.Wf) && (cfb * CFB + pl * 64 + c * 8 < p.Cf);
+                const unsigned voff = ok ? (unsigned)(((ty * p.Wf + tx) * p.Cf + pl * 64 + c * 8) * 2) : RSU_SENT;
                 bdma16(rf, voff, soffF, (void*)(lds + buf * FBUF + j * 1024));
             }
         }
@@ -138,8 +152,8 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             const unsigned soffS = (unsigned)((((long)(T.n * p.S.H + iy0 + p.S.oy) * p.S.W + ix0 + p.S.ox) * p.S.C + csb * CSB) * 2);
             for (int q = 0; q < nsw; ++q) {  // pieces past the halo tile (hp >= npix_max) fail the window test below or are never read
                 const int j = q * NW + wave;
-                const int hp = j * PPP + lane / LPP;
-                const int pc = lane % LPP;
+                const int hp = j * PPP + ln / LPP;
+                const int pc = ln % LPP;
                 const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
                 const int rr = div_magic(hp, p.g.inv_CW);
                 const int cc = hp - rr * CW;
@@ -185,33 +199,41 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds + off));
         };
         auto load_F = [&](int ks, bf16x8(&fa)[CFT]) {
+            const int fk = fb + (kgrp * KSG + ks) * (32 * 128);  // wave-uniform
+            const int a0 = fk + f0[0], a1 = fk + f0[1];  // fk is a multiple of 128: bits 5-6 stay the swizzled block index
 #pragma unroll
             for (int ct = 0; ct < CFT; ++ct) {
-                const bf16x4 lo = tr_read(fb + foff[ks][0][ct]), hi = tr_read(fb + foff[ks][1][ct]);
+                // tiles of one wave never straddle a 64-channel plane and start at a multiple of CFT <= 4 tiles: XOR-ing the tile
+                // index into the block bits is exact ((b0 + ct) ^ m == (b0 ^ m) ^ ct when b0 is a multiple of CFT, CFT a power of two)
+                const bf16x4 lo = tr_read(a0 ^ (ct << 5)), hi = tr_read(a1 ^ (ct << 5));
                 fa[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
         // B operand: S (cols = cs) shifted by the tap
         auto load_S = [&](int ks, int tap, bf16x8(&sv)[CST]) {
             const int ky = tap / KW, kx = tap - ky * KW;
-            const int rowoff = sb + ky * CW * p.dil * SPITCH;  // wave-uniform
+            const int rowoff = sb + ky * CW * p.dil * SPITCH + sdelta(kgrp * KSG + ks);  // wave-uniform
 #pragma unroll
             for (int st = 0; st < CST; ++st) {
-                const bf16x4 lo = tr_read(rowoff + soff[ks][0][kx][st]), hi = tr_read(rowoff + soff[ks][1][kx][st]);
+                const bf16x4 lo = tr_read(rowoff + soff[0][kx][st]), hi = tr_read(rowoff + soff[1][kx][st]);
                 sv[st] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         };
         // one software-pipelined sequence over (k-step, tap): operands of step+1 are requested before the MFMAs of step
         constexpr int NS = KSG * NTAP;
-        bf16x8 fa[2][CFT], sv[2][CST];
+        // F fragments are double-buffered across k-steps unless the wave already holds 64 F channels x all k-steps (128x64
+        // shape: 16 more VGPRs would spill); then they are fetched at the head of each k-step and the partner wave covers the wait
+        constexpr int FB = (KG == 1 && CFT >= 4) ? 1 : 2;
+        bf16x8 fa[FB][CFT], sv[2][CST];
         load_F(0, fa[0]);
         load_S(0, 0, sv[0]);
 #pragma unroll
         for (int step = 0; step < NS; ++step) {
             const int ks = step / NTAP, tap = step % NTAP;
+            if (FB == 1 && tap == 0 && step > 0) load_F(ks, fa[0]);
             if (step + 1 < NS) {
                 const int ks1 = (step + 1) / NTAP, tap1 = (step + 1) % NTAP;
-                if (tap1 == 0) load_F(ks1, fa[ks1 & 1]);
+                if (FB == 2 && tap1 == 0) load_F(ks1, fa[ks1 & (FB - 1)]);
                 load_S(ks1, tap1, sv[(step + 1) & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -219,10 +241,16 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             for (int ct = 0; ct < CFT; ++ct)
 #pragma unroll
                 for (int st = 0; st < CST; ++st)
-                    acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
+                    acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & (FB - 1)][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
             if (tap == 0 && do_bias) {
+                // the all-ones operand is re-materialised here (four v_mov per k-step) instead of living in four VGPRs
+                unsigned o1 = 0x3f803f80u;
+                asm volatile("" : "+v"(o1));
+                const u32x4 o4 = {o1, o1, o1, o1};
+                const bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
 #pragma unroll
-                for (int ct = 0; ct < CFT; ++ct) accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][ct], ones, accb[ct], 0, 0, 0);
+                for (int ct = 0; ct < CFT; ++ct)
+                    accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & (FB - 1)][ct], ones, accb[ct], 0, 0, 0);
             }
         }
         buf = buf + 1 == nbuf ? 0 : buf + 1;
@@ -259,7 +287,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     if (do_bias && l15 == 0) {  // every column of accb holds the same sums: column 0 writes them
 #pragma unroll
         for (int ct = 0; ct < CFT; ++ct) {
-            const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
+            const int cf = cfb * CFB + (wcf * CFT + ct) * 16 + 4 * g4;
             if (cf < p.Cf) *(f32x4*)(p.bslab + (long)zs * p.CfOut + cf) = accb[ct];
         }
     }
@@ -272,7 +300,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             if (cs >= p.S.C) continue;
 #pragma unroll
             for (int ct = 0; ct < CFT; ++ct) {
-                const int cf = cfb * 64 + (wcf * CFT + ct) * 16 + 4 * g4;
+                const int cf = cfb * CFB + (wcf * CFT + ct) * 16 + 4 * g4;
                 if (cf >= p.Cf) continue;
                 float* dst = p.slab + (((long)zs * NTAP + tap) * p.CsOut + p.cs_off + cs) * p.CfOut + cf;
                 *(f32x4*)dst = acc[tap][ct][st];
@@ -283,19 +311,25 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 template <int CFG> struct WgCfg;
 template <> struct WgCfg<IGW_CFG_64x64> { static constexpr int WCF = 1, WCS = 4, CFT = 4, CST = 1, TMK = 128, KG = 2; };
 template <> struct WgCfg<IGW_CFG_64x16> { static constexpr int WCF = 4, WCS = 1, CFT = 1, CST = 1, TMK = 128, KG = 2; };
+// 128 F channels per workgroup, eight waves with their own 64 x 16 output blocks (all k-steps each): a third fewer staging
+// bytes per MFMA than 64x64 (the S halo tile is shared by twice the F channels)
+template <> struct WgCfg<IGW_CFG_128x64> { static constexpr int WCF = 2, WCS = 4, CFT = 4, CST = 1, TMK = 128, KG = 1; };
 
 int igemm_wgrad_kgroups(int) { return 1; }  // wave groups are reduced inside the workgroup: one slab per grid.z slice
-int igemm_wgrad_tmk(int cfg) { return cfg == IGW_CFG_64x64 ? WgCfg<IGW_CFG_64x64>::TMK : WgCfg<IGW_CFG_64x16>::TMK; }
+int igemm_wgrad_tmk(int) { return 128; }
+int igemm_wgrad_cfb(int cfg) { return cfg == IGW_CFG_128x64 ? 128 : 64; }
+int igemm_wgrad_csb(int cfg) { return cfg == IGW_CFG_64x16 ? 16 : 64; }
 
 int igemm_wgrad_nsw(int cfg, int npix_max) {  // S pieces (1 KiB) per wave per tile, 8 waves
-    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
+    const int csb = igemm_wgrad_csb(cfg);
     const int ppp = 64 / (csb / 8);
     return ((npix_max + ppp - 1) / ppp + 7) / 8;
 }
 size_t igemm_wgrad_lds_bytes(int cfg, int npix_max, int nbuf) {
-    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
-    const size_t staging = (size_t)nbuf * igemm_wgrad_tmk(cfg) * 128 + (size_t)nbuf * igemm_wgrad_nsw(cfg, npix_max) * 8 * 1024;
-    const size_t reduce = (size_t)(9 * 64 * csb + 64 * csb) * 4;  // wave-group hand-off of the accumulators (+ bias sums)
+    const int csb = igemm_wgrad_csb(cfg);
+    const size_t staging = (size_t)nbuf * igemm_wgrad_tmk(cfg) * 2 * igemm_wgrad_cfb(cfg) +
+                           (size_t)nbuf * igemm_wgrad_nsw(cfg, npix_max) * 8 * 1024;
+    const size_t reduce = cfg == IGW_CFG_128x64 ? 0 : (size_t)(9 * 64 * csb + 64 * csb) * 4;  // wave-group hand-off (+ bias sums)
     return staging > reduce ? staging : reduce;
 }
 
@@ -320,6 +354,9 @@ hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int gx,
         if (ntap == 4) return wlaunch_one<IGW_CFG_64x64, 4, 2>(p, gx, gy, gz, st);
     } else if (cfg == IGW_CFG_64x16) {
         if (ntap == 9) return wlaunch_one<IGW_CFG_64x16, 9, 3>(p, gx, gy, gz, st);
+    } else if (cfg == IGW_CFG_128x64) {
+        if (ntap == 9) return wlaunch_one<IGW_CFG_128x64, 9, 3>(p, gx, gy, gz, st);
+        if (ntap == 4) return wlaunch_one<IGW_CFG_128x64, 4, 2>(p, gx, gy, gz, st);
     }
     return hipErrorInvalidValue;
 }

@@ -474,34 +474,45 @@ extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, voi
 // ---------------------------------------------------------------------------------------------
 // igemm_wgrad family
 // ---------------------------------------------------------------------------------------------
+// the 64x64 shape is widened to 128 F channels per workgroup whenever F has that many (RSU_WG_CFG=0 keeps 64x64, A/B runs)
+static int wgrad_pick_cfg(int cfg, int Cf) {
+    if (cfg == IGW_CFG_64x64 && Cf >= 128 && env_int("RSU_WG_CFG", IGW_CFG_128x64) == IGW_CFG_128x64) return IGW_CFG_128x64;
+    return cfg;
+}
 // grid.z splits of the pixel reduction: one workgroup per CU in total
-static int wgrad_max_split(int Cf, int Cs, int csb) {
-    int want = 256 / (cdiv(Cf, 64) * cdiv(Cs, csb));
+static int wgrad_max_split(int cfg, int Cf, int Cs) {
+    int want = 256 / (cdiv(Cf, igemm_wgrad_cfb(cfg)) * cdiv(Cs, igemm_wgrad_csb(cfg)));
     return want < 1 ? 1 : want;
 }
-static size_t wgrad_max_slabs(int, int Cf, int Cs, int csb) { return (size_t)wgrad_max_split(Cf, Cs, csb); }
+// slabs the workspace must hold (either shape the launch may pick)
+static size_t wgrad_max_slabs(int cfg, int Cf, int Cs) {
+    const int a = wgrad_max_split(cfg, Cf, Cs), b = wgrad_max_split(wgrad_pick_cfg(cfg, Cf), Cf, Cs);
+    return (size_t)(a > b ? a : b);
+}
 struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw, nbuf; };
 static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
     pl.cfg = cfg;
-    const int csb = cfg == IGW_CFG_64x64 ? 64 : 16;
+    const int csb = igemm_wgrad_csb(cfg), cfbk = igemm_wgrad_cfb(cfg);
     const int tmk = igemm_wgrad_tmk(cfg);
     // three staging buffers (loads two tiles ahead) when a halo tile small enough exists, else two
     bool ok = false;
     for (int nbuf = 3; nbuf >= 2 && !ok; --nbuf) {
-        const long fixed = (long)nbuf * tmk * 128;
+        const long fixed = (long)nbuf * tmk * 2 * cfbk;
+        if (fixed >= 150 * 1024) continue;
         int cap = (int)((160 * 1024 - fixed) / (nbuf * csb * 2));
         const int ppw = 64 / (csb / 8) * 8;  // S pixels covered by one piece per wave
         cap = cap / ppw * ppw;               // the kernel rounds the S slot up to whole pieces per wave
         const int cap5 = 5 * ppw;            // ... and knows wait counts for at most 5 of them
         if (nbuf == 3 && cap > cap5) cap = cap5;
+        if (cap < ppw) continue;
         pl.nbuf = nbuf;
         ok = plan_geo_aligned(pl.g, pl.lsw, Hf, Wf, tmk, kh, kw, dil, stride, cap);
     }
     if (!ok) return false;
-    pl.gx = cdiv(Cf, 64);
+    pl.gx = cdiv(Cf, cfbk);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
-    const int want = wgrad_max_split(Cf, Cs, csb);  // workgroups along z; each writes one slab
+    const int want = wgrad_max_split(cfg, Cf, Cs);  // workgroups along z; each writes one slab
     pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
     (void)ntap;
     return true;
@@ -510,7 +521,9 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
                      int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr) {
     WgPlan pl;
-    if (!plan_wgrad(pl, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
+    const int wide = wgrad_pick_cfg(cfg, Cf);
+    if (wide != cfg && plan_wgrad(pl, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
+    else if (!plan_wgrad(pl, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
     IgWgradParams p;
     memset(&p, 0, sizeof(p));
     p.F = (const bf16_t*)F;
@@ -541,7 +554,7 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
 }
 
 extern "C" size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout) {
-    return wgrad_max_slabs(IGW_CFG_64x64, Cout, src_C, 64) * (9 * (size_t)Cin_total * Cout + Cout);
+    return wgrad_max_slabs(IGW_CFG_64x64, Cout, src_C) * (9 * (size_t)Cin_total * Cout + Cout);
 }
 extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
                                      int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream) {
@@ -553,7 +566,7 @@ extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
-    return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout, 64) * 4 * (size_t)Cout * Cin;
+    return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout) * 4 * (size_t)Cout * Cin;
 }
 extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin, int Cout,
                                        rsu_stream_t stream) {
@@ -565,7 +578,7 @@ extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK,
 }
 
 extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {
-    return (wgrad_max_slabs(IGW_CFG_64x16, Cout, 16, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
+    return (wgrad_max_slabs(IGW_CFG_64x16, Cout, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
 }
 extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N, int H, int W,
                                          int Cout, int dil, rsu_stream_t stream) {
