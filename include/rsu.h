@@ -159,10 +159,11 @@ int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, v
 /* dx bf16 [N][H][W][Cin] = sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci], times (relu_src > 0) if given */
 int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, int N, int H,
                           int W, int Cin, int Cout, rsu_stream_t stream);
-/* dK f32 [2][2][Cout][Cin]; ws: rsu_convT2x2_bwd_weight_ws_floats() floats */
+/* dK f32 [2][2][Cout][Cin] and, when db != NULL, db f32 [Cout] = sum over all pixels of dy (BiasAddGrad of the transposed
+ * conv, unet.py:72) from the same launch; ws: rsu_convT2x2_bwd_weight_ws_floats() floats */
 size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout);
-int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin,
-                            int Cout, rsu_stream_t stream);
+int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W,
+                            int Cin, int Cout, rsu_stream_t stream);
 
 /* ---- optimizer (tf_aerial_images.py:116-121, MomentumOptimizer, use_nesterov=False) ------- */
 /* acc = mu*acc + gscale*g ; w -= lr*acc. gscale folds the 1/world_size of data-parallel averaging. */

@@ -53,7 +53,7 @@ SIGNATURES = {
     "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_convT2x2_bwd_weight_ws_floats": (_sz, [_i, _i]),
-    "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_momentum_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _l, _vp]),
     "rsu_extract_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),

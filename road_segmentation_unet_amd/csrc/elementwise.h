@@ -17,7 +17,9 @@ hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, hi
 hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws, hipStream_t st);
 int ew_colsum_blocks(long npix, int C);
 hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st);
-hipError_t ew_reduce_slabs(const float* slab, float* out, int nsplit, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut, hipStream_t st);
+// out2 (optional): n2 more float4 items behind the taps of every slab, reduced into out2 by the same launch
+hipError_t ew_reduce_slabs(const float* slab, float* out, float* out2, int n2, int nsplit, long slab_elems, int ntap, int CsOut, int cs_off, int cs_cnt,
+                           int CfOut, hipStream_t st);
 int ew_head_blocks(long npix, int C);
 hipError_t ew_head(bool train, const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* logits, void* dact, float* dw,
                    float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st);

@@ -234,46 +234,59 @@ __global__ void __launch_bounds__(256) k_colsum_final(const float* __restrict__ 
 // split-K slab reduction: out[row][col] = sum_z slab[z][row][col] for the rows of one source
 // rows are (tap, cs) pairs: row index -> tap*CsOut + cs_off + cs
 // ---------------------------------------------------------------------------------------------
-__global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntap, int CsOut,
-                               int cs_off, int cs_cnt, int CfOut) {
+// an optional extra row behind the taps of every slab (column sums of F = bias gradient) is reduced into out2 by the same launch
+struct ReduceItem { long e; float* dst; };
+__device__ __forceinline__ bool reduce_item(ReduceItem& it, long tid, long total, float* out, float* out2, int n2, int ntap, int CsOut,
+                                            int cs_off, int cs_cnt, int CfOut) {
     const int cf4 = CfOut >> 2;
-    const long total = (long)ntap * cs_cnt * cf4;
-    const long slab_elems = (long)ntap * CsOut * CfOut;
-    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(tid % cf4);
-        long r = tid / cf4;
-        const int cs = (int)(r % cs_cnt), tap = (int)(r / cs_cnt);
-        const long e = ((long)tap * CsOut + cs_off + cs) * CfOut + c4 * 4;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < nsplit; ++z) t += *(const f32x4*)(slab + z * slab_elems + e);
-        *(f32x4*)(out + e) = t;
-    }
-}
-// many splits, few outputs: 32 float4 outputs x 8 split-lanes per block, fixed-order LDS tree
-__global__ void __launch_bounds__(256) k_reduce_slabs_wide(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntap,
-                                                           int CsOut, int cs_off, int cs_cnt, int CfOut) {
-    __shared__ f32x4 red[256];
-    const int cf4 = CfOut >> 2;
-    const long total = (long)ntap * cs_cnt * cf4;
-    const long slab_elems = (long)ntap * CsOut * CfOut;
-    const int el = threadIdx.x & 31, zp = threadIdx.x >> 5;
-    const long tid = (long)blockIdx.x * 32 + el;
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    long e = 0;
     if (tid < total) {
         const int c4 = (int)(tid % cf4);
         long r = tid / cf4;
         const int cs = (int)(r % cs_cnt), tap = (int)(r / cs_cnt);
-        e = ((long)tap * CsOut + cs_off + cs) * CfOut + c4 * 4;
-        for (int z = zp; z < nsplit; z += 8) t += *(const f32x4*)(slab + z * slab_elems + e);
+        it.e = ((long)tap * CsOut + cs_off + cs) * CfOut + c4 * 4;
+        it.dst = out + it.e;
+        return true;
     }
+    if (out2 && tid < total + n2) {
+        const int c4 = (int)(tid - total);
+        it.e = (long)ntap * CsOut * CfOut + c4 * 4;
+        it.dst = out2 + c4 * 4;
+        return true;
+    }
+    return false;
+}
+__global__ void k_reduce_slabs(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out2, int n2, int nsplit,
+                               long slab_elems, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut) {
+    const long total = (long)ntap * cs_cnt * (CfOut >> 2);
+    const long total2 = total + (out2 ? n2 : 0);
+    for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total2; tid += (long)gridDim.x * blockDim.x) {
+        ReduceItem it;
+        if (!reduce_item(it, tid, total, out, out2, n2, ntap, CsOut, cs_off, cs_cnt, CfOut)) continue;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; ++z) t += *(const f32x4*)(slab + z * slab_elems + it.e);
+        *(f32x4*)it.dst = t;
+    }
+}
+// many splits, few outputs: 32 float4 outputs x 8 split-lanes per block, fixed-order LDS tree
+__global__ void __launch_bounds__(256) k_reduce_slabs_wide(const float* __restrict__ slab, float* __restrict__ out, float* __restrict__ out2,
+                                                           int n2, int nsplit, long slab_elems, int ntap, int CsOut, int cs_off, int cs_cnt,
+                                                           int CfOut) {
+    __shared__ f32x4 red[256];
+    const long total = (long)ntap * cs_cnt * (CfOut >> 2);
+    const int el = threadIdx.x & 31, zp = threadIdx.x >> 5;
+    const long tid = (long)blockIdx.x * 32 + el;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    ReduceItem it;
+    const bool have = reduce_item(it, tid, total, out, out2, n2, ntap, CsOut, cs_off, cs_cnt, CfOut);
+    if (have)
+        for (int z = zp; z < nsplit; z += 8) t += *(const f32x4*)(slab + z * slab_elems + it.e);
     red[threadIdx.x] = t;
     __syncthreads();
-    if (zp == 0 && tid < total) {
+    if (zp == 0 && have) {
         f32x4 r = red[el];
 #pragma unroll
         for (int q = 1; q < 8; ++q) r += red[q * 32 + el];
-        *(f32x4*)(out + e) = r;
+        *(f32x4*)it.dst = r;
     }
 }
 
@@ -622,14 +635,15 @@ hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hip
     hipLaunchKernelGGL(k_colsum_final, dim3((C + 31) / 32), dim3(256), 0, st, ws, db, nb, C);
     return hipGetLastError();
 }
-hipError_t ew_reduce_slabs(const float* slab, float* out, int nsplit, int ntap, int CsOut, int cs_off, int cs_cnt, int CfOut,
-                           hipStream_t st) {
-    const long total = (long)ntap * cs_cnt * (CfOut / 4);
+hipError_t ew_reduce_slabs(const float* slab, float* out, float* out2, int n2, int nsplit, long slab_elems, int ntap, int CsOut, int cs_off,
+                           int cs_cnt, int CfOut, hipStream_t st) {
+    const long total = (long)ntap * cs_cnt * (CfOut / 4) + (out2 ? n2 : 0);
     if (nsplit >= 16 && (total + 31) / 32 < 0x7fffffffL)
-        hipLaunchKernelGGL(k_reduce_slabs_wide, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off,
-                           cs_cnt, CfOut);
+        hipLaunchKernelGGL(k_reduce_slabs_wide, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slab, out, out2, n2, nsplit, slab_elems, ntap,
+                           CsOut, cs_off, cs_cnt, CfOut);
     else
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, nsplit, ntap, CsOut, cs_off, cs_cnt, CfOut);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, out2, n2, nsplit, slab_elems, ntap, CsOut,
+                           cs_off, cs_cnt, CfOut);
     return hipGetLastError();
 }
 int ew_head_blocks(long npix, int C) {

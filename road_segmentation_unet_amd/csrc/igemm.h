@@ -64,7 +64,9 @@ struct IgWgradParams {
     int Hf, Wf, Cf;     // F tensor [N][Hf][Wf][Cf]; the pixel grid of the reduction
     IgSrc S;
     float* slab;        // [nsplit][ntap][CsOut][CfOut]
-    float* bslab;       // [nsplit][CfOut] per-split column sums of F (BiasAddGrad when F = dz), or null
+    float* bslab;       // per-split column sums of F (BiasAddGrad when F = dz), or null: split z at bslab + z*slab_stride
+    float* sbslab;      // per-split column sums of S over all taps (bias gradient of the transposed conv, where S = dy), or null
+    long slab_stride;   // floats between the slabs of consecutive splits (>= ntap*CsOut*CfOut; the bias row may sit behind the taps)
     int CsOut, CfOut, cs_off;
     const void* zero_page;
     int N, dil, stride;

@@ -75,6 +75,12 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     f32x4 accb[CFT];
 #pragma unroll
     for (int a = 0; a < CFT; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ... and the column sums of S over every tap (ones x S): the bias gradient of the transposed conv (S = dy, taps = the four
+    // disjoint output phases), in the waves of cf block 0
+    const bool do_sbias = (p.sbslab != nullptr) && (cfb == 0) && (wcf == 0);
+    f32x4 accs[CST];
+#pragma unroll
+    for (int b = 0; b < CST; ++b) accs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane byte offsets of the transposed LDS reads (workgroup constants) for the lane's pixel INSIDE a 32-pixel k-step;
     // the k-step itself adds a compile-time constant to the F offset (32 pixels x 128 bytes) and a scalar to the S offset
@@ -242,6 +248,14 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
                 for (int st = 0; st < CST; ++st)
                     acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & (FB - 1)][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
+            if (do_sbias) {
+                unsigned o1 = 0x3f803f80u;
+                asm volatile("" : "+v"(o1));
+                const u32x4 o4 = {o1, o1, o1, o1};
+                const bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+#pragma unroll
+                for (int st = 0; st < CST; ++st) accs[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, sv[step & 1][st], accs[st], 0, 0, 0);
+            }
             if (tap == 0 && do_bias) {
                 // the all-ones operand is re-materialised here (four v_mov per k-step) instead of living in four VGPRs
                 unsigned o1 = 0x3f803f80u;
@@ -271,6 +285,10 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                     for (int b = 0; b < CST; ++b) red[((t * CFT + a) * CST + b) * (WCF * WCS * 64) + slot] = acc[t][a][b];
 #pragma unroll
             for (int a = 0; a < CFT; ++a) red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot] = accb[a];
+            if (NTAP < 9) {  // (the 9-tap hand-off already fills the 160 KiB; only the transposed conv carries S sums)
+#pragma unroll
+                for (int b = 0; b < CST; ++b) red[((NTAP * CFT + CFT) * CST + b) * (WCF * WCS * 64) + slot] = accs[b];
+            }
         }
         __syncthreads();
         if (kgrp == 1) return;
@@ -283,12 +301,23 @@ igemm_wgrad_kernel(const IgWgradParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < CFT; ++a) accb[a] += red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot];
+        if (NTAP < 9) {
+#pragma unroll
+            for (int b = 0; b < CST; ++b) accs[b] += red[((NTAP * CFT + CFT) * CST + b) * (WCF * WCS * 64) + slot];
+        }
+    }
+    if (do_sbias && g4 == 0) {  // every row of accs holds the same sums: row 0 (lanes 0..15, element 0) writes them
+#pragma unroll
+        for (int st = 0; st < CST; ++st) {
+            const int cs = csb * CSB + (wcs * CST + st) * 16 + l15;
+            if (cs < p.S.C) p.sbslab[(long)zs * p.slab_stride + cs] = accs[st][0];
+        }
     }
     if (do_bias && l15 == 0) {  // every column of accb holds the same sums: column 0 writes them
 #pragma unroll
         for (int ct = 0; ct < CFT; ++ct) {
             const int cf = cfb * CFB + (wcf * CFT + ct) * 16 + 4 * g4;
-            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)zs * p.CfOut + cf) = accb[ct];
+            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)zs * p.slab_stride + cf) = accb[ct];
         }
     }
     // ---- write this split's slab: D rows = cf (4 consecutive per lane), cols = cs
@@ -302,7 +331,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             for (int ct = 0; ct < CFT; ++ct) {
                 const int cf = cfb * CFB + (wcf * CFT + ct) * 16 + 4 * g4;
                 if (cf >= p.Cf) continue;
-                float* dst = p.slab + (((long)zs * NTAP + tap) * p.CsOut + p.cs_off + cs) * p.CfOut + cf;
+                float* dst = p.slab + (long)zs * p.slab_stride + (((long)tap * p.CsOut + p.cs_off + cs) * p.CfOut + cf);
                 *(f32x4*)dst = acc[tap][ct][st];
             }
         }

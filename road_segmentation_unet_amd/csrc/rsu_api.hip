@@ -519,7 +519,7 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
 }
 
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
-                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr) {
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
     WgPlan pl;
     const int wide = wgrad_pick_cfg(cfg, Cf);
     if (wide != cfg && plan_wgrad(pl, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
@@ -531,9 +531,17 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.S.ptr = (const bf16_t*)S->ptr;
     p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
     const int nslab = pl.nsplit;
-    // a single split needs no slab: its workgroups write the gradient (and the bias sums) in place
+    // a single split needs no slab: its workgroups write the gradient (and the bias sums) in place; otherwise the bias sums are
+    // one more row behind the taps of each slab, so a single reduce launch finishes both
+    const long main_elems = (long)ntap * CsOut * CfOut;
+    // extra items behind the taps of each slab: the F column sums (db, CfOut floats) or the S column sums (dbs, CsOut floats)
+    if (db && dbs) return RSU_EINVAL;
+    const int extra = db ? CfOut : (dbs ? rup(CsOut, 4) : 0);
     p.slab = nslab == 1 ? out : ws;
-    p.bslab = db ? (nslab == 1 ? db : ws + (size_t)nslab * ntap * CsOut * CfOut) : nullptr;
+    p.slab_stride = main_elems + extra;
+    p.bslab = db ? (nslab == 1 ? db : ws + main_elems) : nullptr;
+    p.sbslab = dbs ? (nslab == 1 ? dbs : ws + main_elems) : nullptr;
+    if (dbs && (CsOut % 4 || cs_off != 0 || S->C != CsOut)) return RSU_EINVAL;
     p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
@@ -547,8 +555,7 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.g = pl.g;
     HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
     if (nslab > 1) {
-        HIP_CHECK_RET(ew_reduce_slabs(ws, out, nslab, ntap, CsOut, cs_off, S->C, CfOut, st));
-        if (db) HIP_CHECK_RET(ew_reduce_slabs(p.bslab, db, nslab, 1, 1, 0, 1, CfOut, st));
+        HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
     }
     return RSU_OK;
 }
@@ -566,15 +573,15 @@ extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
-    return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout) * 4 * (size_t)Cout * Cin;
+    return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout) * (4 * (size_t)Cout * Cin + Cout);
 }
-extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* ws, int N, int H, int W, int Cin, int Cout,
-                                       rsu_stream_t stream) {
+extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W, int Cin,
+                                       int Cout, rsu_stream_t stream) {
     if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
     // F = x (cf = ci), S = dy (cs = co), stride 2: slab[tap(a,b)][co][ci] = K layout
-    return run_wgrad(IGW_CFG_64x64, x, H, W, Cin, &s, dK, ws, Cout, Cin, 0, N, 4, 2, 1, 2, (hipStream_t)stream);
+    return run_wgrad(IGW_CFG_64x64, x, H, W, Cin, &s, dK, ws, Cout, Cin, 0, N, 4, 2, 1, 2, (hipStream_t)stream, nullptr, db);
 }
 
 extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {

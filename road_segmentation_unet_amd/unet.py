@@ -392,9 +392,8 @@ class UNet:
             upin = a["c2_%d" % (j - 1)] if i > 0 else a["c2_%d" % (L - 1)]
             gin = g["c2_%d" % (j - 1)] if i > 0 else g["c2_%d" % (L - 1)]
             hh = h // 2
-            call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.ws), B, hh, hh,
-                 upin.shape[3], nf, st)
-            call("rsu_bias_grad", _ptr(dup), _ptr(self.g["up_conv_%d/bias" % i]), _ptr(self.ws), B * h * h, nf, st)
+            call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
+                 _ptr(self.ws), B, hh, hh, upin.shape[3], nf, st)
             call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), B, hh, hh,
                  upin.shape[3], nf, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final

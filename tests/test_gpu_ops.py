@@ -259,8 +259,10 @@ def test_convT(N, H, W, Cin, Cout):
     hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx), "convT bwd_data")
     dK = torch.full((2, 2, Cout, Cin), float("nan"), dtype=torch.float32, device=hu.DEV)
     ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(Cin, Cout), dtype=torch.float32, device=hu.DEV)
-    call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(ws), N, H, W, Cin, Cout, hu.stream())
+    dbT = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+    call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(dbT), hu.ptr(ws), N, H, W, Cin, Cout, hu.stream())
     hu.assert_f32_close(hu.host(dK), rdK, "convT bwd_weight")
+    hu.assert_f32_close(hu.host(dbT), rdb, "convT bias grad fused in bwd_weight")
 
 
 # ------------------------------------------------------------------------------------------- head, optimizer

@@ -27,5 +27,5 @@ for _ in range(5):
     elif op == "bwd":
         call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), B, h, h, cin, cout, st)
     else:
-        call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), ptr(ws), B, h, h, cin, cout, st)
+        call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), None, ptr(ws), B, h, h, cin, cout, st)
 torch.cuda.synchronize()
