@@ -151,59 +151,61 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             w_cur += stage_bytes;
         }
     };
-    // halo tile of stream chunk gc (tile T): exactly NA pieces per wave; clipped / padded pixels come back as zeros
-    unsigned amask = 0;  // bit q: piece q of this lane lies inside the source window for the tile being prefetched
-    auto prep_a = [&](const Tile& T) {
-        const int iy0 = T.y0 * p.stride - p.pad, ix0 = T.x0 * p.stride - p.pad;
-        amask = 0;
-#pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int hp = (q * NW + wave) * 16 + lq;
-            const int rr = div_magic(hp, p.g.inv_CW);
-            const int cc = hp - rr * CW;
-            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win);
-            amask |= ok ? (1u << q) : 0u;
-        }
-    };
-    int a_cl = 0;    // chunk (inside its tile) of the next halo to prefetch
-    int ia_slot = 0; // its ring slot
-    auto issue_a = [&](const Tile& T) {
-        int si = 0, cl = a_cl;
-        a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
-        if (cl >= p.nchunk[0]) {
-            cl -= p.nchunk[0];
-            si = 1;
-            if (cl >= p.nchunk[1]) {
-                cl -= p.nchunk[1];
-                si = 2;
-            }
-        }
+    // ---- halo prefetch stream: exactly NA pieces per wave per chunk; clipped / padded pixels come back as zeros.
+    // Everything that depends only on (tile, source) is computed once per (tile, source) by setup_a and carried in registers:
+    // the per-lane byte offsets of the NA pieces (already RSU_SENT where the pixel falls outside the window), the source base
+    // and the scalar offset of the halo origin. A chunk then costs one scalar add and, per piece, an M0 write and the DMA.
+    unsigned a_voff[NA];           // per-lane byte offset of piece q inside the current source, or RSU_SENT
+    const char* a_ptr = nullptr;   // current source, shifted back by the padding so that every in-window offset is >= 0
+    unsigned a_soff = 0;           // byte offset of the (padded) halo origin + channel chunk in that source
+    int a_crem = 0;                // channels left in the current source (>= 32 except in a partial last chunk)
+    int a_cl = 0;                  // chunk (inside its tile) of the next halo to prefetch
+    int a_next_src = 0;            // chunk index at which the next source begins
+    int a_si = 0;                  // current source
+    int ia_slot = 0;               // ring slot of the next halo
+    auto setup_a = [&](const Tile& T, int si) {
         const bf16_t* sptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
         const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
         const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
         const int sC = si == 0 ? p.src[0].C : (si == 1 ? p.src[1].C : p.src[2].C);
         const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
         const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
-        const int c0 = cl * 32;
-        // descriptor base is shifted back by the padding so that every in-window offset is >= 0
-        const __amdgpu_buffer_rsrc_t rs = mk(sptr - ((long)p.pad * sW + p.pad) * sC);
-        // scalar byte offset of the (padded) halo origin in this source, plus the channel chunk
-        const unsigned soff = (unsigned)((((long)(T.n * sH + T.y0 * p.stride + soy) * sW + (T.x0 * p.stride + sox)) * sC + c0) * 2);
-        const int dst = a_base + ia_slot * ABUF;
-        ia_slot = ia_slot == NAB - 1 ? 0 : ia_slot + 1;
-        const int crem = sC - c0;  // channels left in this source (>= 32 except in a partial last chunk)
+        a_ptr = (const char*)(sptr - ((long)p.pad * sW + p.pad) * sC);
+        a_soff = (unsigned)((((long)(T.n * sH + T.y0 * p.stride + soy) * sW + (T.x0 * p.stride + sox)) * sC) * 2);
+        a_crem = sC;
+        const int iy0 = T.y0 * p.stride - p.pad, ix0 = T.x0 * p.stride - p.pad;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int j = q * NW + wave;
-            const int hp = j * 16 + lq;
+            const int hp = (q * NW + wave) * 16 + lq;
             const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
             const int rr = div_magic(hp, p.g.inv_CW);
             const int cc = hp - rr * CW;
-            const bool ok = ((amask >> q) & 1u) && (kg8 < crem);
-            const unsigned voff = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
-            const int d = j < npieces ? dst + j * 1024 : dummy_base;
-            bdma16(rs, voff, soff, (void*)(lds + d));
+            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win);
+            a_voff[q] = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
         }
+    };
+    auto issue_a = [&]() {
+        const __amdgpu_buffer_rsrc_t rs = mk(a_ptr);
+        const int dst = a_base + ia_slot * ABUF;
+        ia_slot = ia_slot == NAB - 1 ? 0 : ia_slot + 1;
+        if (a_crem >= 32) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int j = q * NW + wave;
+                bdma16(rs, a_voff[q], a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+            }
+        } else {  // partial last chunk of a source whose channel count is not a multiple of 32: the missing channels read as zeros
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int j = q * NW + wave;
+                const int hp = j * 16 + lq;
+                const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
+                bdma16(rs, kg8 < a_crem ? a_voff[q] : RSU_SENT, a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+            }
+        }
+        a_soff += 64;
+        a_crem -= 32;
+        a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
     };
 
     // bias of this workgroup's TN channels lives in LDS (behind the scratch slot): read back at every tile start with
@@ -283,16 +285,25 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     // ---- prologue: A(0), W(0), W(1)
     Tile ptile = decode(0);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
-    prep_a(ptile);
+    setup_a(ptile, 0);
+    a_next_src = p.nchunk[0];
     bool a_started = false;
-    auto issue_a_next = [&]() {  // halo of the next chunk of the stream (moves on to the next tile after a tile's last chunk)
-        if (a_cl == 0 && a_started) {
-            ++pk;
-            ptile = decode(pk);
-            prep_a(ptile);
+    auto issue_a_next = [&]() {  // halo of the next chunk of the stream (moves on to the next source / tile where one ends)
+        if (a_cl == 0) {
+            if (a_started) {
+                ++pk;
+                ptile = decode(pk);
+                a_si = 0;
+                a_next_src = p.nchunk[0];
+                setup_a(ptile, 0);
+            }
+        } else if (a_cl == a_next_src) {
+            ++a_si;
+            a_next_src += a_si == 1 ? p.nchunk[1] : p.nchunk[2];
+            setup_a(ptile, a_si);
         }
         a_started = true;
-        issue_a(ptile);
+        issue_a();
     };
     if constexpr (SPC == 1) {
         // the issues of the DW stages "before" stage 0, in steady-state order (halo of stage k+DA, then weights of stage k+DW)
@@ -404,13 +415,32 @@ igemm_fwd2_kernel(const IgFwdParams p) {
 
 // ---------------------------------------------------------------------------------------------
 template <int CFG> struct Fwd2Cfg;
-// NA = halo DMA pieces per wave per chunk (NA * NW * 16 pixels of halo at most)
-template <> struct Fwd2Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 4; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 6; };
-template <> struct Fwd2Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 3; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 4; };
-template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> { static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8, NA = 7; };
-template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> { static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8, NA = 10; };
+// na(ntap) = halo DMA pieces per wave per chunk (every wave issues exactly that many: na * NW * 16 halo pixels at most). 3x3: a
+// TM-pixel tile plus its halo; 2x2 stride 2 (transposed-conv backward-data): 4*TM pixels; 1x1: TM pixels
+template <> struct Fwd2Cfg<IGF2_CFG_128x256> {
+    static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4;
+    static constexpr int na(int ntap) { return ntap == 1 ? 2 : 4; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_64x512> {
+    static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4;
+    static constexpr int na(int ntap) { return ntap == 1 ? 4 : 6; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_128x128> {
+    static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2;
+    static constexpr int na(int ntap) { return ntap == 1 ? 1 : (ntap == 4 ? 4 : 3); }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_64x256> {
+    static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2;
+    static constexpr int na(int ntap) { return ntap == 1 ? 2 : 4; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> {
+    static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8;
+    static constexpr int na(int) { return 7; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> {
+    static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8;
+    static constexpr int na(int) { return 10; }
+};
 
 static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
 static constexpr int nab_for(int TN, int ntap) { return ntap / tps2_for(TN, ntap) == 1 ? 4 : 2; }
@@ -429,9 +459,9 @@ IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
     }
     return IgFwdCfgInfo{0, 0, 0};
 }
-int igemm_fwd2_max_pieces(int cfg) {
+int igemm_fwd2_max_pieces(int cfg, int ntap) {
     switch (cfg) {
-#define CASE(C) case C: return Fwd2Cfg<C>::NA * Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::WPX;
+#define CASE(C) case C: return Fwd2Cfg<C>::na(ntap) * Fwd2Cfg<C>::WCO * Fwd2Cfg<C>::WPX;
         CASE(IGF2_CFG_128x256)
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
@@ -453,7 +483,7 @@ static hipError_t launch2_one(const IgFwdParams& p, int gx, int gy, hipStream_t 
     using C = Fwd2Cfg<CFG>;
     constexpr int TN = C::WCO * C::CT * 16;
     constexpr int TPS = tps2_for(TN, NTAP);
-    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::NA, nab_for(TN, NTAP)>;
+    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::na(NTAP), nab_for(TN, NTAP)>;
     const size_t lds = igemm_fwd2_lds_bytes(CFG, NTAP, p.g.npix_max);
     static size_t lds_set = 0;
     if (lds > lds_set) {

@@ -314,7 +314,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
         const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, ntap, 1) - fixed;  // 64 bytes x halo ring slots
         int cap = (int)((160 * 1024 - fixed) / per_pix);
-        const int cap2 = igemm_fwd2_max_pieces(cfg) * 16;
+        const int cap2 = igemm_fwd2_max_pieces(cfg, ntap) * 16;
         if (cap2 < cap) cap = cap2;
         TileGeo g;
         int lsw = 0;
