@@ -176,6 +176,16 @@ def main():
     n_launch = sum(a[2] for a in agg.values())
     achieved = conv_fl / conv_t / 1e12 if conv_t > 0 else 0.0
     tot_fl, conv3_fl = net_flops(L, root, args.dilated_layers, P, B)
+    # HBM-side bytes per conv launch: PMC counters cannot be read from inside this process; the figure is the one measured with
+    # tools/pmc_traffic.sh on this same workload and committed under profiles/rNN/traffic.json (null for any other workload)
+    traffic = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+        if cands and (L, root, P, B, args.dilated_layers) == (5, 64, 388, 4, False):
+            traffic = json.load(open(cands[-1]))["kernels"]["conv3x3 all"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
 
     out = {
         "metric": "388x388 patches/sec fwd+bwd (1/2/4/8 GPU) + conv MFMA % of peak",
@@ -195,7 +205,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "step_tflops_algorithmic": tot_fl * world * args.steps / dt / 1e12, "loss": loss},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "kernel": "3x3 conv MFMA kernels: igemm_fwd (fwd, bwd-data) + igemm_wgrad",
                      "launches_per_step": n_launch // nprof,
                      "avg_launch_us": conv_t / max(1, n_launch) * 1e6,

@@ -396,19 +396,20 @@ template __global__ void k_head<false>(const bf16_t*, const float*, const float*
 
 __global__ void __launch_bounds__(256) k_head_final(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                     float* __restrict__ loss_sum, int nblk, int C) {
+    // 8 outputs x 32 partial lanes per block (a lane walks nblk/32 partials: short dependent chains), fixed-order LDS tree
     __shared__ float red[256];
     const int nout = 2 * C + 3;
-    const int ol = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int o = blockIdx.x * 32 + ol;
+    const int ol = threadIdx.x & 7, part = threadIdx.x >> 3;
+    const int o = blockIdx.x * 8 + ol;
     float t = 0.f;
     if (o < nout)
-        for (int bk = part; bk < nblk; bk += 8) t += partial[(long)bk * nout + o];
+        for (int bk = part; bk < nblk; bk += 32) t += partial[(long)bk * nout + o];
     red[threadIdx.x] = t;
     __syncthreads();
     if (part == 0 && o < nout) {
         float r = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r += red[q * 32 + ol];
+        for (int q = 0; q < 32; ++q) r += red[q * 8 + ol];
         if (o < 2 * C) dw[o] = r;
         else if (o < 2 * C + 2) db[o - 2 * C] = r;
         else loss_sum[0] += r;
@@ -658,7 +659,7 @@ hipError_t ew_head(bool train, const void* act, const float* w, const float* b, 
     const int nb = ew_head_blocks(npix, C);
     if (train) {
         hipLaunchKernelGGL(k_head<true>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, labels, prob, logits, (bf16_t*)dact, ws, npix, C, inv_count);
-        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 31) / 32), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
+        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 7) / 8), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
     } else {
         hipLaunchKernelGGL(k_head<false>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, nullptr, prob, logits, nullptr, nullptr, npix, C, 0.f);
     }

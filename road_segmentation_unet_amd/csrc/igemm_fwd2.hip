@@ -18,12 +18,14 @@
 
 #define RSU_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int SPC, int WPS, int NA, int DA>
+template <int SPC, int WPS, int NA, int DA, int DW>
 __device__ __forceinline__ constexpr int vm_allowed(int j) {
     // loads that may still be in flight when stage position j starts (issue order: see the kernel body).
     // SPC == 1 (one stage per chunk, halo DA chunks ahead, weights DA+1 stages ahead): everything issued after the halo of
     // this stage = the weights of that same stage position plus the complete issues of the DA-1 stages since
-    return SPC == 1 ? WPS + (DA - 1) * (NA + WPS) : (j == 0 ? WPS : WPS + NA);
+    // SPC > 1 (halo one chunk ahead, issued behind the weights of stage position 0; weights DW <= SPC stages ahead): the weights
+    // of the DW-1 stages since, plus the next chunk's halo unless this is position 0 (whose own halo is the youngest load it needs)
+    return SPC == 1 ? WPS + (DA - 1) * (NA + WPS) : (j == 0 ? (DW - 1) * WPS : (DW - 1) * WPS + NA);
 }
 
 // buffer -> LDS copy of 16 bytes per lane: out-of-range lanes (voffset + soffset >= num_records) deposit ZEROS, which is
@@ -47,7 +49,7 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
 // NAB = halo ring slots (prefetch distance NAB-1 chunks), NAB+1 weight slots (distance NAB stages). 2 for the 3x3 kernels
 // (a chunk is three stages long, one chunk ahead is plenty); deeper for the one-stage-per-chunk kernels (1x1 / transposed
 // conv), whose stages are too short to cover a load's latency
-template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA, int NAB>
+template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA, int NAB, int DWS>
 __global__ void __launch_bounds__(WCO* WPX * 64) __attribute__((amdgpu_waves_per_eu(WCO* WPX / 4, WCO* WPX / 4)))
 igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int NW = WCO * WPX;
@@ -56,12 +58,13 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int WT = TN / 16;
     constexpr int SPC = NTAP / TPS;
     constexpr int WBUF = TPS * WT * 1024;
-    constexpr int NWB = NAB + 1;               // weight ring slots
-    constexpr int DA = NAB - 1, DW = NAB;      // prefetch distances: halo (chunks), weights (stages)
+    constexpr int DA = NAB - 1, DW = DWS;      // prefetch distances: halo (chunks), weights (stages)
+    constexpr int NWB = DW + 1;                // weight ring slots
     constexpr int WPS = (TPS * WT + NW - 1) / NW;  // weight DMA instructions per wave per stage (padded to a constant)
     constexpr int NST = (CT / 2) * PT;         // epilogue buffer stores per wave per tile (always issued)
     static_assert(NTAP % TPS == 0 && (CT % 2) == 0 && SPC <= 3, "bad config");
-    static_assert(SPC == 1 || NAB == 2, "deep rings only for one-stage-per-chunk kernels");
+    static_assert(SPC == 1 || NAB == 2, "deep halo rings only for one-stage-per-chunk kernels");
+    static_assert(SPC == 1 ? DW == NAB : (DW >= 2 && DW <= SPC), "weight distance");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
     const int ABUF = p.g.npix_max * 64;
@@ -313,9 +316,11 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             if (k + DW < GC) issue_w();
         }
     } else {
-        issue_a_next();
         issue_w();
-        if (GC * SPC > 1) issue_w();
+        issue_a_next();
+#pragma unroll
+        for (int k = 1; k < DW; ++k)
+            if (k < GC * SPC) issue_w();
     }
 
     int gc = 0;      // stream chunk counter
@@ -334,16 +339,16 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
             // every wave may rely on the constant per-stage counts only while the two chunks ahead exist
-            const bool steady = (gc + DW < GC) && (SPC > 1 || nchunks >= DA);
+            const bool steady = SPC == 1 ? (gc + DW < GC && nchunks >= DA) : (gc + 2 < GC);
             // first stages after an epilogue: its 16-byte stores sit in the VMEM queue behind the loads these stages wait for
             const bool after_epi = SPC == 1 ? (c < DA && ck > 0) : ((c == 0) && gc > 0);
             auto stage = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const int st = gc * SPC + j;
-                constexpr int ALLOWED = vm_allowed<SPC, WPS, NA, DA>(j);
+                constexpr int ALLOWED = vm_allowed<SPC, WPS, NA, DA, DW>(j);
                 if (!steady) {
                     RSU_WAIT_VMCNT(0);
-                } else if (after_epi && j < 2) {
+                } else if (after_epi && j < DW) {
                     RSU_WAIT_VMCNT(ALLOWED + NST);
                 } else {
                     RSU_WAIT_VMCNT(ALLOWED);
@@ -372,7 +377,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                         if (gc + DA < GC && !(p.dbg & 2)) issue_a_next();
                         if (st + DW < GC * SPC && !(p.dbg & 1)) issue_w();
                     } else {
-                        if (st + 2 < GC * SPC && !(p.dbg & 1)) issue_w();
+                        if (st + DW < GC * SPC && !(p.dbg & 1)) issue_w();
                         if (j == 0 && gc + 1 < GC && !(p.dbg & 2)) issue_a_next();
                     }
                 };
@@ -444,6 +449,9 @@ template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> {
 
 static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
 static constexpr int nab_for(int TN, int ntap) { return ntap / tps2_for(TN, ntap) == 1 ? 4 : 2; }
+// weight prefetch distance in stages: = halo ring depth for the one-stage-per-chunk kernels, else 2 (3 was measured on the PT = 2
+// 3x3 shapes: no gain -- their waits are barrier skew, not load latency)
+static constexpr int dws_for(int TN, int ntap, int PT) { return ntap / tps2_for(TN, ntap) == 1 ? nab_for(TN, ntap) : 2; }
 
 IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
     switch (cfg) {
@@ -475,7 +483,9 @@ int igemm_fwd2_max_pieces(int cfg, int ntap) {
 size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max) {
     const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
     const int tps = tps2_for(ci.TN, ntap), nab = nab_for(ci.TN, ntap);
-    return (size_t)(nab + 1) * tps * (ci.TN / 16) * 1024 + (size_t)nab * npix_max * 64 + 1024 + 512;
+    const int pt = ci.TM / 16 / (ci.threads / 64 / (ci.TN / 64));  // PT = TM / 16 / WPX, WPX = waves / WCO, WCO = TN / 64
+    const int dws = dws_for(ci.TN, ntap, pt);
+    return (size_t)(dws + 1) * tps * (ci.TN / 16) * 1024 + (size_t)nab * npix_max * 64 + 1024 + 512;
 }
 
 template <int CFG, int NTAP, int KW>
@@ -483,7 +493,7 @@ static hipError_t launch2_one(const IgFwdParams& p, int gx, int gy, hipStream_t 
     using C = Fwd2Cfg<CFG>;
     constexpr int TN = C::WCO * C::CT * 16;
     constexpr int TPS = tps2_for(TN, NTAP);
-    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::na(NTAP), nab_for(TN, NTAP)>;
+    auto kern = igemm_fwd2_kernel<C::WCO, C::WPX, C::CT, C::PT, NTAP, KW, TPS, C::na(NTAP), nab_for(TN, NTAP), dws_for(TN, NTAP, C::PT)>;
     const size_t lds = igemm_fwd2_lds_bytes(CFG, NTAP, p.g.npix_max);
     static size_t lds_set = 0;
     if (lds > lds_set) {
