@@ -31,9 +31,16 @@ class GradBucketer:
     Call ready(lo) when every gradient at positions >= lo has been produced (monotonically decreasing lo), then
     finish() before the optimizer step."""
 
-    def __init__(self, flat, n_live, group=None, min_bucket_elems=1 << 20):
+    def __init__(self, flat, n_live, group=None, min_bucket_elems=1 << 20, overlap=None):
         self.flat, self.n_live, self.group = flat, n_live, group
         self.min_bucket = min_bucket_elems
+        # overlap=False (or RSU_DP_OVERLAP=0): one all-reduce of the whole buffer in finish(). The conv kernels are persistent,
+        # one workgroup per CU with the whole register file: RCCL's channel blocks and they cannot share a CU, so overlapped
+        # buckets trade hidden communication against stretched conv launches -- measure both on the target node.
+        if overlap is None:
+            import os
+            overlap = os.environ.get("RSU_DP_OVERLAP", "1") != "0"
+        self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
@@ -57,6 +64,8 @@ class GradBucketer:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def ready(self, lo):
+        if not self.overlap:
+            return
         lo = max(0, min(lo, self.hi))
         if self.hi - lo >= self.min_bucket:
             self._launch(lo, self.hi)
