@@ -1,17 +1,25 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel-trace stats of the same command.
-# usage: tools/gpu_bench_profile.sh <tag> [bench args...]
-set -u
-TAG=${1:-r01}; shift || true
+# usage: tools/gpu_bench_profile.sh <tag>  (on the GPU box) -> gpurun_out/bench_<tag>.json, gpurun_out/prof_<tag>/ (+ kernel stats csv)
+TAG=$1
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out
-mkdir -p $OUT
-cd $REPO
-python3 bench.py --steps 10 --warmup 3 "$@" > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
-echo "bench rc=$?"; tail -c 3000 $OUT/bench_$TAG.json; tail -5 $OUT/bench_$TAG.err
+mkdir -p $REPO/gpurun_out
+python3 $REPO/bench.py --steps 20 --warmup 3 > $REPO/gpurun_out/bench_$TAG.json 2> $REPO/gpurun_out/bench_$TAG.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o prof -- python3 $REPO/bench.py --steps 5 --warmup 2 --no_cpu_baseline "$@" > $OUT/prof_$TAG.log 2>&1
-echo "rocprof rc=$?"
-find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -40 {}'
-# keep only the small summaries (the full trace can be large)
-find $OUT/prof_$TAG -name "*kernel_trace.csv" -size +20M -delete
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_$TAG -o $TAG -- python3 $REPO/bench.py --steps 10 --warmup 2 --no_cpu_baseline > $REPO/gpurun_out/prof_$TAG.log 2>&1
+python3 - <<PY
+import sqlite3, glob, csv
+db = sqlite3.connect(glob.glob("$REPO/gpurun_out/prof_$TAG/*.db")[0])
+cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if "kernel_dispatch" in t][0]
+ks = [t for t in tabs if "kernel_symbol" in t][0]
+rows = cur.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+with open("$REPO/gpurun_out/${TAG}_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for n, c, t, a, mn, mx in rows:
+        w.writerow([n, c, t, "%.1f" % a, "%.2f" % (100.0 * t / tot), mn, mx])
+print("kernels:", len(rows), "total ms:", tot / 1e6)
+PY
+cut -c1-300 $REPO/gpurun_out/bench_$TAG.json
