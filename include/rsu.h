@@ -84,10 +84,15 @@ int rsu_pack_table_finish(void* host_table, int nentries, int* total_blocks);
 int rsu_pack_table_run(const void* dev_table, int nentries, int total_blocks, rsu_stream_t stream);
 
 /* ---- network head / tail (VALU kernels) -------------------------------------------------- */
-/* unet.py:22-23  net = conv1x1(X - 0.5) (color_space_adjust). x: f32 [npix][3].
- * out16: bf16 [npix][16] = {net0[0..2], 0, (x-0.5)[0..2], 0, 0 x 8} -- channels 0..2 feed the first
- * 3x3 conv, channels 4..6 are kept for the weight gradient of color_space_adjust. */
-int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix,
+/* Dropout (unet.py:29-30, 64-65: tf.nn.dropout(net, keep) = net / keep * floor(keep + U[0,1))) is fused into the producer of
+ * every tensor it applies to. `keep` in (0, 1]; 1.0 = identity (inference, --dropout=1.0). U is a counter-based hash of
+ * (`key`, NHWC element index) -- TensorFlow's Philox stream cannot be reproduced; the parity tests restate the hash bit
+ * for bit on the CPU. The host picks one key per dropout site and step. The backward kernels take the same (keep, key). */
+/* unet.py:22-23  net = conv1x1(X - 0.5) (color_space_adjust), then the level-0 dropout. x: f32 [npix][3].
+ * out16: bf16 [npix][16] = {dropout(net0)[0..2], 0, m[cj]*(x-0.5)[ci] at 4+3*ci+cj, m[0..2] at 13..15} (m = 0/1 keep
+ * mask, all ones without dropout) -- channels 0..2 feed the first 3x3 conv, channels 4..15 are kept for the weight and
+ * bias gradients of color_space_adjust (rsu_conv_first_bwd_weight). */
+int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix, float keep, unsigned key,
                          rsu_stream_t stream);
 /* unet.py:34-35,42-43 first 3x3 conv of level 0 (Cin = 3) + bias + ReLU, dil = 1 or 2 (dilated branch).
  * in16 as above [N][H][W][16]; packed = rsu_pack_conv_first(w f32 HWIO [3][3][3][Cout]) (rows for channels 3..15 are
@@ -96,12 +101,15 @@ size_t rsu_packed_first_bytes(int Cout);
 int rsu_pack_conv_first(const float* w_hwio, void* packed, int Cout, rsu_stream_t stream);
 int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout,
                        int dil, rsu_stream_t stream);
-/* weight/bias gradients of that conv and, through it, of color_space_adjust:
- * dw1 [3][3][3][Cout], gxc [3][3][3][Cout] where gxc[t][ci][co] = sum_pix (x-0.5)[pix+t][ci] dz[pix][co].
+/* weight/bias gradients of that conv and, through it, of color_space_adjust (no input-gradient pass is needed):
+ * dw1 [3][3][3][Cout]; gx [9][12][Cout]: rows 0..8 gxc[t][3*ci+cj][co] = sum_pix m[pix+t][cj] (x-0.5)[pix+t][ci] dz[pix][co],
+ * rows 9..11 gm[t][cj][co] = sum_pix m[pix+t][cj] dz[pix][co]. With W1 = this conv's kernel:
+ *   d(color_space_adjust/kernel)[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] gxc[t][3*ci+cj][co]
+ *   d(color_space_adjust/bias)[cj]       = 1/keep * sum_{t,co} W1[t][cj][co] gm[t][cj][co]
  * ws: float workspace of rsu_conv_first_bwd_ws_floats() floats. */
 size_t rsu_conv_first_bwd_ws_floats(int Cout);
 /* db (optional): BiasAddGrad of this conv, computed by the same launch */
-int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N,
+int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gx, float* db, float* ws, int N,
                               int H, int W, int Cout, int dil, rsu_stream_t stream);
 /* unet.py:95 weight_output 1x1 conv (C -> 2) fused with tf_aerial_images.py:147-148 softmax[...,1].
  * act bf16 [npix][C]; w f32 [C][2]; prob f32 [npix]; logits f32 [npix][2] or NULL (unet.forward's return value). */
@@ -142,23 +150,29 @@ size_t rsu_bias_grad_ws_floats(long npix, int C);
 int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_stream_t stream);
 
 /* ---- 2x2 max pool -------------------------------------------------------------------------- */
-/* unet.py:52 max_pooling2d (2,2)/(2,2) VALID. x bf16 [N][H][W][C] -> y [N][H/2][W/2][C] */
-int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, rsu_stream_t stream);
+/* unet.py:52 max_pooling2d (2,2)/(2,2) VALID, then the next level's dropout (unet.py:29-30; keep = 1: none).
+ * x bf16 [N][H][W][C] -> y [N][H/2][W/2][C] */
+int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key,
+                       rsu_stream_t stream);
 /* Gradient junction at an encoder output y_act (ReLU output, bf16 [N][H][W][C]):
- *   g = MaxPoolGrad(y_act, dpool)            (dpool bf16 [N][H/2][W/2][C], may be NULL)
+ *   g = MaxPoolGrad(y_act, dropout_grad(dpool))  (dpool bf16 [N][H/2][W/2][C], may be NULL; (keep, key) as in
+ *                                             rsu_maxpool2x2_fwd: dpool is the gradient of the DROPPED pooled tensor)
  *     + zero-pad(dskip)                      (dskip bf16 [N][Hs][Ws][C] centred, may be NULL;
  *                                             adjoint of the centre crop of unet.py:70-83)
  *   dz = g * (y_act > 0)                     (ReluGrad) -> bf16 [N][H][W][C]
  * MaxPoolGrad routes to the first maximum of the window in row-major order. */
 int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W,
-                           int C, int Hs, int Ws, rsu_stream_t stream);
+                           int C, int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream);
+/* unet.py:64-65 dropout in front of a transposed conv: y = x / keep * floor(keep + U), bf16 [n] -> bf16 [n] (n % 8 == 0).
+ * Its backward is fused into rsu_convT2x2_bwd_data: pass y as relu_src (y > 0 <=> x > 0 and kept) and out_scale = 1/keep. */
+int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsigned key, rsu_stream_t stream);
 
 /* ---- 2x2 stride-2 transposed convolution (unet.py:67-68) ---------------------------------- */
 int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W,
                      int Cin, int Cout, rsu_stream_t stream);
-/* dx bf16 [N][H][W][Cin] = sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci], times (relu_src > 0) if given */
-int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, int N, int H,
-                          int W, int Cin, int Cout, rsu_stream_t stream);
+/* dx bf16 [N][H][W][Cin] = out_scale * sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci], times (relu_src > 0) if given */
+int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, float out_scale,
+                          int N, int H, int W, int Cin, int Cout, rsu_stream_t stream);
 /* dK f32 [2][2][Cout][Cin] and, when db != NULL, db f32 [Cout] = sum over all pixels of dy (BiasAddGrad of the transposed
  * conv, unet.py:72) from the same launch; ws: rsu_convT2x2_bwd_weight_ws_floats() floats */
 size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout);

@@ -248,23 +248,52 @@ def init_params(num_layers, root_size, dilated_layers, seed=2018, bias_scale=0.0
 # ----------------------------------------------------------------------------------------------
 # whole network
 # ----------------------------------------------------------------------------------------------
+def dropout_key(seed, site, step):
+    """32-bit key of dropout site `site` (encoder level i -> i, decoder stage i -> L + i) at optimizer step `step`"""
+    return (int(seed) * 0x9E3779B9 + int(site) * 0x85EBCA6B + int(step) * 0xC2B2AE35) & 0xFFFFFFFF
+
+
+def dropout_mask(shape, keep, key):
+    """floor(keep + U) of tf.nn.dropout (unet.py:29-30,64-65) with U = hash(key, NHWC element index) / 2^24 -- the counter-based
+    stand-in for TF's Philox stream that the HIP kernels use (TF's own stream cannot be reproduced). float32 0/1 array."""
+    n = int(np.prod(shape))
+    assert n <= 0xFFFFFFFF
+    with np.errstate(over="ignore"):
+        h = np.arange(n, dtype=np.uint32) ^ np.uint32(key)
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.floor(np.float32(keep) + u).astype(np.float32).reshape(shape)
+
+
 def _q(t, emu):
     return round_bf16(t) if emu else t
 
 
-def forward(params, X, num_layers, root_size, dilated_layers, emulate_bf16=False, keep_cache=True):
-    """unet.forward (unet.py:12-97) with dropout_keep = 1.0 (identity). Returns (logits, cache)."""
+def forward(params, X, num_layers, root_size, dilated_layers, emulate_bf16=False, keep_cache=True, keep=1.0, seed=0, step=0):
+    """unet.forward (unet.py:12-97). keep = dropout_keep (1.0: identity); (seed, step) select the dropout masks.
+    Returns (logits, cache)."""
     emu = emulate_bf16
+    inv_keep = np.float32(1.0) / np.float32(keep)
+
+    def drop(t, site):  # x / keep * floor(keep + U), unet.py:30,65
+        if keep >= 1.0:
+            return None
+        return dropout_mask(t.shape, keep, dropout_key(seed, site, step)) * inv_keep
     q = lambda t: _q(t, emu)  # noqa: E731
     qw = lambda name: _q(params[name], emu)  # MFMA kernels read bf16 copies of the weights  # noqa: E731
     cache = {}
     X = _c(X)
     # unet.py:22-23
-    net = q(conv1x1_fwd(X, params["color_space_adjust/kernel"][0, 0], params["color_space_adjust/bias"], sub=0.5))
-    cache["net0"] = net
+    net = conv1x1_fwd(X, params["color_space_adjust/kernel"][0, 0], params["color_space_adjust/bias"], sub=0.5)
     skips = []
     for i in range(num_layers):
-        inp = net
+        mk = drop(net, i)
+        cache["mk_%d" % i] = mk
+        inp = q(net * mk) if mk is not None else q(net)  # (level 0: the one bf16 rounding of net0; pooled tensors are bf16 already)
         cache["in_%d" % i] = inp
         first = False  # (level-0 conv1 also runs on the MFMA kernel with bf16 weight copies)
         dil_out = None
@@ -286,6 +315,11 @@ def forward(params, X, num_layers, root_size, dilated_layers, emulate_bf16=False
     net = skips.pop()[0]
     for i in range(num_layers - 1):
         j = num_layers + i
+        cache["uporig_%d" % i] = net
+        mk = drop(net, num_layers + i)
+        cache["mk_%d" % (num_layers + i)] = mk
+        if mk is not None:
+            net = q(net * mk)
         cache["upin_%d" % i] = net
         up = q(convT_fwd(net, qw("up_conv_%d/kernel" % i), params["up_conv_%d/bias" % i]))
         skip, dskip = skips.pop()
@@ -311,14 +345,14 @@ def predict_probs(params, X, num_layers, root_size, dilated_layers, emulate_bf16
     return softmax_ce(logits)[0]
 
 
-def loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emulate_bf16=False):
+def loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emulate_bf16=False, keep=1.0, seed=0, step=0):
     """Forward + mean sparse softmax CE (tf_aerial_images.py:103-110) + full backward.
     Returns (loss, probs, grads dict keyed by TF variable name)."""
     emu = emulate_bf16
     q = lambda t: _q(t, emu)  # noqa: E731
     qw = lambda name: _q(params[name], emu)  # noqa: E731
     L = num_layers
-    logits, c = forward(params, X, L, root_size, dilated_layers, emu)
+    logits, c = forward(params, X, L, root_size, dilated_layers, emu, keep=keep, seed=seed, step=step)
     probs, loss, dlogits = softmax_ce(logits, labels)
     g = {}
     last = c["last"]
@@ -359,11 +393,14 @@ def loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emu
         upin = c["upin_%d" % i]
         dupin, dK, dbk = convT_bwd(upin, qw("up_conv_%d/kernel" % i), dup)
         g["up_conv_%d/kernel" % i], g["up_conv_%d/bias" % i] = dK, dbk
-        # upin is the ReLU output of the previous block's conv2 (c2 of level L-1 for i=0, of conv_{j-1} otherwise)
+        # the transposed conv's input is (the dropped copy of) the ReLU output of the previous block's conv2
+        mk = c["mk_%d" % j]
+        if mk is not None:
+            dupin = dupin * mk
         if i > 0:
-            dz = q(relu_bwd(upin, dupin))
+            dz = q(relu_bwd(c["uporig_%d" % i], dupin))
         else:
-            dz_bottom = q(relu_bwd(upin, dupin))
+            dz_bottom = q(relu_bwd(c["uporig_%d" % i], dupin))
 
     # encoder, level L-1 .. 0
     dpool = None  # gradient wrt the pooled tensor feeding level i+1
@@ -372,7 +409,8 @@ def loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emu
         if i == L - 1:
             dz2 = dz_bottom if L > 1 else dz
         else:
-            gsum = maxpool_bwd(y2, dpool) + center_pad_like(dskips[i][0], y2.shape)
+            mk = c["mk_%d" % (i + 1)]  # the pooled tensor went through the next level's dropout
+            gsum = maxpool_bwd(y2, dpool * mk if mk is not None else dpool) + center_pad_like(dskips[i][0], y2.shape)
             dz2 = q(relu_bwd(y2, gsum))
         first = (i == 0)
         dx_main, _ = conv_block_bwd("conv_%d/conv1" % i, "conv_%d/conv2" % i, c["in_%d" % i], c["c1_%d" % i], y2, dz2,
@@ -391,6 +429,8 @@ def loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emu
                 g["conv_dilut_%d/%s/bias" % (i, nm)] = np.zeros_like(params["conv_dilut_%d/%s/bias" % (i, nm)])
         dpool = q(dx) if i > 0 else dx
     # color_space_adjust: dnet0 = dpool (gradient wrt net0, fp32 here)
+    if c["mk_0"] is not None:
+        dpool = _c(dpool * c["mk_0"])
     _, dw0, db0 = conv1x1_bwd(_c(X), params["color_space_adjust/kernel"][0, 0], dpool, sub=0.5, need_dx=False)
     g["color_space_adjust/kernel"] = dw0.reshape(1, 1, 3, 3)
     g["color_space_adjust/bias"] = db0
@@ -403,9 +443,10 @@ def learning_rate(lr0, global_step):
 
 
 def train_step(params, accums, X, labels, num_layers, root_size, dilated_layers, lr0=0.01, momentum=0.9,
-               global_step=0, emulate_bf16=False):
+               global_step=0, emulate_bf16=False, keep=1.0, seed=0):
     """One session.run of [train, loss, predictions] (tf_aerial_images.py:241-244). Updates params/accums in place."""
-    loss, probs, grads = loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emulate_bf16)
+    loss, probs, grads = loss_and_grads(params, X, labels, num_layers, root_size, dilated_layers, emulate_bf16, keep=keep, seed=seed,
+                                        step=global_step)
     lr = float(learning_rate(lr0, global_step))
     for name in params:
         momentum_step(params[name], accums[name], grads[name], lr, momentum)

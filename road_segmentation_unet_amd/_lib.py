@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSU_LIB_PATH") or os.path.join(_HERE, "librsu_hip.so")  # RSU_LIB_PATH: developer A/B of two builds
 
-_vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _l, _f, _sz, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 
 
 class RsuSrc(ctypes.Structure):
@@ -33,7 +33,8 @@ SIGNATURES = {
     "rsu_pack_table_add": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _PI, _i]),
     "rsu_pack_table_finish": (_i, [_vp, _i, _PI]),
     "rsu_pack_table_run": (_i, [_vp, _i, _i, _vp]),
-    "rsu_color_adjust_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
+    "rsu_color_adjust_fwd": (_i, [_vp, _vp, _vp, _vp, _l, _f, _u, _vp]),
+    "rsu_dropout_fwd": (_i, [_vp, _vp, _l, _f, _u, _vp]),
     "rsu_packed_first_bytes": (_sz, [_i]),
     "rsu_pack_conv_first": (_i, [_vp, _vp, _i, _vp]),
     "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -48,10 +49,10 @@ SIGNATURES = {
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
     "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
-    "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsu_pool_skip_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),
+    "rsu_pool_skip_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
     "rsu_convT2x2_bwd_weight_ws_floats": (_sz, [_i, _i]),
     "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_momentum_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _l, _vp]),

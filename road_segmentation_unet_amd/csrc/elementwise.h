@@ -10,11 +10,13 @@ struct PackParams {
     int flip;                   // read source tap (ntap-1-tap)
 };
 
-hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, hipStream_t st);
+hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, float keep, unsigned key, hipStream_t st);
+hipError_t ew_dropout(const void* x, void* y, long n, float keep, unsigned key, hipStream_t st);
 hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil, hipStream_t st);
 hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st);
-hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, hipStream_t st);
-hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws, hipStream_t st);
+hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st);
+hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws,
+                                 float keep, unsigned key, hipStream_t st);
 int ew_colsum_blocks(long npix, int C);
 hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st);
 // out2 (optional): n2 more float4 items behind the taps of every slab, reduced into out2 by the same launch

@@ -19,19 +19,57 @@ static __device__ __forceinline__ u32x4 pack8(const float* f) {
 // ---------------------------------------------------------------------------------------------
 // unet.py:22-23  color_space_adjust
 // ---------------------------------------------------------------------------------------------
+// tf.nn.dropout (unet.py:29-30, 64-65): y = x / keep * floor(keep + U[0,1)). TensorFlow's Philox stream cannot be reproduced, so
+// U comes from a counter-based hash of (key, element index) that the test-side CPU restatement reproduces bit for bit. key = f(seed, dropout site, step) is chosen by the host; element index = NHWC linear index of the tensor being dropped.
+__device__ __forceinline__ float drop_keep(unsigned key, unsigned idx, float keep) {
+    unsigned h = idx ^ key;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return floorf(keep + u);  // 1 = kept, 0 = dropped
+}
+
+// out16 = { dropout(net0)[0..2], 0, m[cj] * (x-0.5)[ci] at 4 + 3*ci + cj, m[0..2] at 13..15 } with m = 1 without dropout
 __global__ void k_color_adjust(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                               bf16_t* __restrict__ out16, long npix) {
+                               bf16_t* __restrict__ out16, long npix, float keep, unsigned key) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    const float x0 = x[3 * p] - 0.5f, x1 = x[3 * p + 1] - 0.5f, x2 = x[3 * p + 2] - 0.5f;
-    float f[8];
+    const float xc[3] = {x[3 * p] - 0.5f, x[3 * p + 1] - 0.5f, x[3 * p + 2] - 0.5f};
+    float m[3] = {1.f, 1.f, 1.f};
+    float inv = 1.f;
+    if (keep < 1.f) {
+        inv = 1.f / keep;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) f[c] = fmaf(x2, w[6 + c], fmaf(x1, w[3 + c], fmaf(x0, w[c], b[c])));
+        for (int c = 0; c < 3; ++c) m[c] = drop_keep(key, (unsigned)(3 * p + c), keep);
+    }
+    float f[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = fmaf(xc[2], w[6 + c], fmaf(xc[1], w[3 + c], fmaf(xc[0], w[c], b[c]))) * (m[c] * inv);
     f[3] = 0.f;
-    f[4] = x0; f[5] = x1; f[6] = x2; f[7] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int cj = 0; cj < 3; ++cj) f[4 + 3 * ci + cj] = xc[ci] * m[cj];
+#pragma unroll
+    for (int cj = 0; cj < 3; ++cj) f[13 + cj] = m[cj];
     u32x4* o = (u32x4*)(out16 + 16 * p);
     o[0] = pack8(f);
-    o[1] = u32x4{0u, 0u, 0u, 0u};
+    o[1] = pack8(f + 8);
+}
+
+// generic dropout of a bf16 tensor (decoder: input of each transposed conv), 8 elements per thread
+__global__ void k_dropout(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8, float keep, unsigned key) {
+    const float inv = 1.f / keep;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(*(const u32x4*)(x + 8 * t), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= drop_keep(key, (unsigned)(8 * t + i), keep) * inv;
+        *(u32x4*)(y + 8 * t) = pack8(v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,18 +129,20 @@ __global__ void __launch_bounds__(256) k_conv_first_fwd(const bf16_t* __restrict
 }
 
 // rows 0..2 / 4..6 of the [9][16][Cout] narrow weight-gradient block -> dw1 / gxc [9][3][Cout]
-__global__ void k_scatter_first_grads(const float* __restrict__ tmp, float* __restrict__ dw1, float* __restrict__ gxc, int Cout) {
+__global__ void k_scatter_first_grads(const float* __restrict__ tmp, float* __restrict__ dw1, float* __restrict__ gx, int Cout) {
+    // tmp [9][16][Cout] -> dw1 [9][3][Cout] (rows 0..2) and gx [9][12][Cout] (rows 4..15: 9 masked (x-0.5) products, 3 mask sums)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 27 * Cout) return;
-    const int co = i % Cout, r = i / Cout, ci = r % 3, tap = r / 3;
-    dw1[i] = tmp[((long)tap * 16 + ci) * Cout + co];
-    if (gxc) gxc[i] = tmp[((long)tap * 16 + 4 + ci) * Cout + co];
+    if (i >= 9 * 12 * Cout) return;
+    const int co = i % Cout, r = i / Cout, row = r % 12, tap = r / 12;
+    if (gx) gx[i] = tmp[((long)tap * 16 + 4 + row) * Cout + co];
+    if (row < 3) dw1[((long)tap * 3 + row) * Cout + co] = tmp[((long)tap * 16 + row) * Cout + co];
 }
 
 // ---------------------------------------------------------------------------------------------
 // 2x2 max pool forward
 // ---------------------------------------------------------------------------------------------
-__global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C) {
+__global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, float keep, unsigned key) {
+    const float inv = keep < 1.f ? 1.f / keep : 1.f;
     const int Ho = H >> 1, Wo = W >> 1, ncg = C >> 3;
     const long total = (long)N * Ho * Wo * ncg;
     for (long tid = (long)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (long)gridDim.x * blockDim.x) {
@@ -119,7 +159,12 @@ __global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__
         unpack8(*(const u32x4*)(p + (long)W * C + C), d);
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], d[i]));
-        *(u32x4*)(y + ((long)(n * Ho + oy) * Wo + ox) * C + cg * 8) = pack8(a);
+        const long oidx = ((long)(n * Ho + oy) * Wo + ox) * C + cg * 8;
+        if (keep < 1.f) {  // dropout of the next level's input (unet.py:29-30), fused
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] *= drop_keep(key, (unsigned)(oidx + i), keep) * inv;
+        }
+        *(u32x4*)(y + oidx) = pack8(a);
     }
 }
 
@@ -129,7 +174,8 @@ __global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 __global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const bf16_t* __restrict__ dpool,
                                      const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dz, int N, int H, int W, int C,
-                                     int Hs, int Ws) {
+                                     int Hs, int Ws, float keep, unsigned key) {
+    const float inv = keep < 1.f ? 1.f / keep : 1.f;
     const int Hw = (H + 1) >> 1, Ww = (W + 1) >> 1, ncg = C >> 3;
     const int Hp = H >> 1, Wp = W >> 1;
     const int oy0 = (H - Hs) / 2, ox0 = (W - Ws) / 2;
@@ -162,7 +208,12 @@ __global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const bf16
         }
         if (dpool && wy < Hp && wx < Wp) {
             float dp[8];
-            unpack8(*(const u32x4*)(dpool + ((long)(n * Hp + wy) * Wp + wx) * C + cg * 8), dp);
+            const long pidx = ((long)(n * Hp + wy) * Wp + wx) * C + cg * 8;
+            unpack8(*(const u32x4*)(dpool + pidx), dp);
+            if (keep < 1.f) {  // the pooled tensor went through dropout: same mask, same scale
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dp[i] *= drop_keep(key, (unsigned)(pidx + i), keep) * inv;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int best = 0;
@@ -595,8 +646,12 @@ static inline int grid_for(long total, int block, int cap = 256 * 16) {
     return (int)g;
 }
 
-hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, hipStream_t st) {
-    hipLaunchKernelGGL(k_color_adjust, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, w, b, (bf16_t*)out16, npix);
+hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void* out16, long npix, float keep, unsigned key, hipStream_t st) {
+    hipLaunchKernelGGL(k_color_adjust, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, w, b, (bf16_t*)out16, npix, keep, key);
+    return hipGetLastError();
+}
+hipError_t ew_dropout(const void* x, void* y, long n, float keep, unsigned key, hipStream_t st) {
+    hipLaunchKernelGGL(k_dropout, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / 8, keep, key);
     return hipGetLastError();
 }
 hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil,
@@ -608,19 +663,19 @@ hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, v
     return hipGetLastError();
 }
 hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st) {
-    hipLaunchKernelGGL(k_scatter_first_grads, dim3((27 * Cout + 255) / 256), dim3(256), 0, st, tmp, dw1, gxc, Cout);
+    hipLaunchKernelGGL(k_scatter_first_grads, dim3((9 * 12 * Cout + 255) / 256), dim3(256), 0, st, tmp, dw1, gxc, Cout);
     return hipGetLastError();
 }
-hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, hipStream_t st) {
+hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st) {
     const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, keep, key);
     return hipGetLastError();
 }
 hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs,
-                                 int Ws, hipStream_t st) {
+                                 int Ws, float keep, unsigned key, hipStream_t st) {
     const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(k_pool_skip_relu_bwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)yact, (const bf16_t*)dpool,
-                       (const bf16_t*)dskip, (bf16_t*)dz, N, H, W, C, Hs, Ws);
+                       (const bf16_t*)dskip, (bf16_t*)dz, N, H, W, C, Hs, Ws, keep, key);
     return hipGetLastError();
 }
 int ew_colsum_blocks(long npix, int C) {

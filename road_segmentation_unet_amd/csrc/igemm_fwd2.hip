@@ -245,6 +245,8 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
                 const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
                 voffs[e] = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
+                mk4[e] = u32x4{0u, 0u, 0u, 0u};
+                ob4[e] = u32x4{0u, 0u, 0u, 0u};
                 if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
                 if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
             }
@@ -256,6 +258,12 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 for (int i = 0; i < 4; ++i) {
                     v[i] = acc[2 * pp][pt][i];
                     v[4 + i] = acc[2 * pp + 1][pt][i];
+                }
+                if (p.oscale != 1.f) {  // (the scale goes through a VGPR: the packed multiply by the scalar argument came out wrong)
+                    float os = p.oscale;
+                    asm volatile("" : "+v"(os));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(os));
                 }
                 if (p.mask_src) {
 #pragma unroll

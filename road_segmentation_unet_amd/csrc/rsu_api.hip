@@ -262,9 +262,16 @@ extern "C" int rsu_pack_table_run(const void* dev_table, int nentries, int total
 // ---------------------------------------------------------------------------------------------
 // VALU head / tail
 // ---------------------------------------------------------------------------------------------
-extern "C" int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix, rsu_stream_t stream) {
-    if (!x || !w || !b || !out16 || npix < 1) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_color_adjust(x, w, b, out16, npix, (hipStream_t)stream));
+static bool keep_ok(float keep) { return keep > 0.f && keep <= 1.f; }
+extern "C" int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* out16, long npix, float keep, unsigned key,
+                                    rsu_stream_t stream) {
+    if (!x || !w || !b || !out16 || npix < 1 || 3 * npix > 0xffffffffL || !keep_ok(keep)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_color_adjust(x, w, b, out16, npix, keep, key, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsigned key, rsu_stream_t stream) {
+    if (!x || !y || n < 8 || n % 8 || n > 0xffffffffL || !keep_ok(keep)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_dropout(x, y, n, keep, key, (hipStream_t)stream));
     return RSU_OK;
 }
 // ---------------------------------------------------------------------------------------------
@@ -346,7 +353,8 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
-                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st,
+                   float oscale = 1.f) {
     const int kh = ntap / kw;
     const long out_bytes = (long)N * oH * oW * outC * 2;
     bool gen2 = env_int("RSU_FWD_GEN", 2) == 2 && out_bytes < 0x7ffffff0L;
@@ -386,6 +394,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.dil = dil; p.stride = stride; p.pad = pad;
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
+    p.oscale = oscale;
     if (use2) {
         p.ncob = pl2.ncob;
         p.g = pl2.g;
@@ -462,13 +471,13 @@ extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const flo
                    2, 4, 0, 0, (hipStream_t)stream);
 }
 
-extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, int N, int H, int W, int Cin,
-                                     int Cout, rsu_stream_t stream) {
-    if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, float out_scale, int N, int H,
+                                     int W, int Cin, int Cout, rsu_stream_t stream) {
+    if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2 || !(out_scale > 0.f)) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
     return run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0, H, W,
-                   1, 1, 0, 0, (hipStream_t)stream);
+                   1, 1, 0, 0, (hipStream_t)stream, out_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,16 +619,17 @@ extern "C" int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, in
 // ---------------------------------------------------------------------------------------------
 // pool, head, optimizer, tiler
 // ---------------------------------------------------------------------------------------------
-extern "C" int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, rsu_stream_t stream) {
-    if (!x || !y || C % 8 || H < 2 || W < 2) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_maxpool_fwd(x, y, N, H, W, C, (hipStream_t)stream));
+extern "C" int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, rsu_stream_t stream) {
+    if (!x || !y || C % 8 || H < 2 || W < 2 || !keep_ok(keep)) return RSU_EINVAL;
+    if (keep < 1.f && (long)N * (H / 2) * (W / 2) * C > 0xffffffffL) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_maxpool_fwd(x, y, N, H, W, C, keep, key, (hipStream_t)stream));
     return RSU_OK;
 }
 extern "C" int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C,
-                                      int Hs, int Ws, rsu_stream_t stream) {
-    if (!y_act || !dz || C % 8) return RSU_EINVAL;
+                                      int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream) {
+    if (!y_act || !dz || C % 8 || !keep_ok(keep)) return RSU_EINVAL;
     if (dskip && (Hs > H || Ws > W || Hs < 1 || Ws < 1)) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_pool_skip_relu_bwd(y_act, dpool, dskip, dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, (hipStream_t)stream));
+    HIP_CHECK_RET(ew_pool_skip_relu_bwd(y_act, dpool, dskip, dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, keep, key, (hipStream_t)stream));
     return RSU_OK;
 }
 static bool head_c_ok(int C) { return C >= 8 && C <= 512 && (C % 8) == 0 && ((C / 8) & (C / 8 - 1)) == 0; }

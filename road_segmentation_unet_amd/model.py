@@ -95,6 +95,7 @@ class ConvolutionalModel:
         # the reference's graph is static in (batch, patch): one UNet serves training and (zero-padded) prediction batches
         self.net = UNet(opts.num_layers, opts.root_size, opts.dilated_layers, self.local_batch, opts.patch_size, device=device,
                         params=params, seed=opts.seed, training=True)
+        self.net.dropout_seed = int(opts.seed) + 7919 * self.rank  # independent masks on every rank's shard
         self._bucketer = None
         if self.world > 1:
             self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
@@ -108,12 +109,11 @@ class ConvolutionalModel:
         """One session.run([train, loss, predictions]) (tf_aerial_images.py:241-244) on this rank's shard.
         patches [b,S,S,3] float, labels [b,P,P] in {0,1}; returns (global mean loss tensor, predictions [b,P,P] device tensor)."""
         opts, net = self._options, self.net
-        if float(opts.dropout) != 1.0:
-            raise NotImplementedError("the HIP path implements dropout keep probability 1.0 only (pass --dropout=1.0, as the "
-                                      "reference's final model does, README.md:65)")
         net.x.copy_(torch.as_tensor(patches).to(net.device, torch.float32))
         net.labels.copy_(torch.as_tensor(labels).to(net.device, torch.int64))
-        net.forward_device()
+        # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
+        # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
+        net.forward_device(keep=float(opts.dropout))
         if self._bucketer is not None:
             self._bucketer.reset()
         net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))

@@ -98,6 +98,8 @@ class UNet:
         self.S = input_size_needed(patch_size, num_layers)
         self.device = torch.device(device)
         self.training = training
+        self.keep = 1.0        # dropout keep probability of the forward pass in flight (set by forward_device)
+        self.dropout_seed = int(seed) if seed is not None else 0
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
@@ -208,7 +210,7 @@ class UNet:
                 if n.startswith("up_conv") and n.endswith("kernel"):
                     ws.append(lib.rsu_convT2x2_bwd_weight_ws_floats(s[3], s[2]))
             self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
-            self.gfirst = torch.zeros((2, 3, 3, 3, self.root), dtype=torch.float32, device=dev)  # gxc of conv1 / atrous_conv1
+            self.gfirst = torch.zeros((2, 9, 12, self.root), dtype=torch.float32, device=dev)  # gx of conv1 / atrous_conv1 (rsu.h)
 
     def _conv_sources_c(self, name, shape):
         """channel counts of the concat sources feeding conv `name` (decoder conv1: [skip,(dil skip),up], unet.py:79/85)"""
@@ -297,11 +299,19 @@ class UNet:
                     _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
                     self._stream())
 
-    def forward_device(self, want_logits=False):
-        """unet.forward (unet.py:12-97) on self.x (already on device) with dropout_keep = 1.0; fills self.prob."""
+    def dropout_key(self, site):
+        """32-bit key of dropout site `site` (encoder level i -> i, decoder stage i -> L + i: the 2L-1 tf.nn.dropout calls of
+        unet.py:29-30,64-65) for the current global step; the hash of (key, element index) replaces TF's Philox stream"""
+        return (self.dropout_seed * 0x9E3779B9 + site * 0x85EBCA6B + self.global_step * 0xC2B2AE35) & 0xFFFFFFFF
+
+    def forward_device(self, want_logits=False, keep=1.0):
+        """unet.forward (unet.py:12-97) on self.x (already on device); keep = dropout_keep (1.0: none); fills self.prob."""
         B, L, S, st, a = self.B, self.L, self.S, self._stream(), self.act
+        keep = float(keep)
+        assert 0.0 < keep <= 1.0, "dropout keep probability must be in (0, 1]"
+        self.keep = keep
         call("rsu_color_adjust_fwd", _ptr(self.x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
-             _ptr(self.in16), B * S * S, st)
+             _ptr(self.in16), B * S * S, keep, self.dropout_key(0), st)
         cur, h = None, S
         for i in range(L):
             last = i == L - 1
@@ -320,12 +330,18 @@ class UNet:
             self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
             if not last:
                 c2 = a["c2_%d" % i]
-                call("rsu_maxpool2x2_fwd", _ptr(c2), _ptr(a["pool_%d" % i]), B, h - 4, h - 4, c2.shape[3], st)
+                call("rsu_maxpool2x2_fwd", _ptr(c2), _ptr(a["pool_%d" % i]), B, h - 4, h - 4, c2.shape[3], keep, self.dropout_key(i + 1), st)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
         for i in range(L - 1):
             j, lvl = L + i, L - 2 - i
             up = a["up_%d" % i]
+            if keep < 1.0:  # unet.py:64-65
+                drop = a.get("drop_%d" % i)
+                if drop is None:
+                    drop = a["drop_%d" % i] = torch.zeros_like(net)
+                call("rsu_dropout_fwd", _ptr(net), _ptr(drop), net.numel(), keep, self.dropout_key(L + i), st)
+                net = drop
             call("rsu_convT2x2_fwd", _ptr(net), _ptr(self.pk["up_conv_%d/kernel" % i, "fwd"]), _ptr(self.w["up_conv_%d/bias" % i]), _ptr(up),
                  B, h, h, net.shape[3], up.shape[3], st)
             h = 2 * h
@@ -367,6 +383,7 @@ class UNet:
     def backward_device(self, inv_count):
         """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count)."""
         B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
+        keep = self.keep
         last = a[self.last_name]
         self.loss_sum.zero_()
         call("rsu_head_fwd_bwd", _ptr(last), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.labels),
@@ -391,10 +408,12 @@ class UNet:
             # transposed conv
             upin = a["c2_%d" % (j - 1)] if i > 0 else a["c2_%d" % (L - 1)]
             gin = g["c2_%d" % (j - 1)] if i > 0 else g["c2_%d" % (L - 1)]
+            if keep < 1.0:  # the transposed conv read the dropped tensor; (dropped > 0) = ReLU mask AND keep mask
+                upin = a["drop_%d" % i]
             hh = h // 2
             call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
                  _ptr(self.ws), B, hh, hh, upin.shape[3], nf, st)
-            call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), B, hh, hh,
+            call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), float(np.float32(1.0) / np.float32(keep)), B, hh, hh,
                  upin.shape[3], nf, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
         # ---- encoder, level L-1 .. 0
@@ -406,7 +425,8 @@ class UNet:
             if i < L - 1:
                 dec = L - 2 - i
                 hs = a["up_%d" % dec].shape[1]
-                call("rsu_pool_skip_relu_bwd", _ptr(c2), _ptr(g["pool_%d" % i]), _ptr(g["skip_%d" % dec]), _ptr(dz2), B, h - 4, h - 4, nf, hs, hs, st)
+                call("rsu_pool_skip_relu_bwd", _ptr(c2), _ptr(g["pool_%d" % i]), _ptr(g["skip_%d" % dec]), _ptr(dz2), B, h - 4, h - 4, nf, hs, hs,
+                     keep, self.dropout_key(i + 1), st)
             self._wgrad("conv_%d/conv2" % i, [(c1, h - 2)], dz2, h - 4)
             self._bwd_data("conv_%d/conv2" % i, dz2, dz1, h - 2, relu_src=c1)
             if i > 0:
@@ -421,7 +441,7 @@ class UNet:
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
                 dec = L - 2 - i
                 hs = a["up_%d" % dec].shape[1]
-                call("rsu_pool_skip_relu_bwd", _ptr(d2), None, _ptr(g["skipd_%d" % dec]), _ptr(dzd2), B, h - 8, h - 8, nf, hs, hs, st)
+                call("rsu_pool_skip_relu_bwd", _ptr(d2), None, _ptr(g["skipd_%d" % dec]), _ptr(dzd2), B, h - 8, h - 8, nf, hs, hs, 1.0, 0, st)
                 self._wgrad("conv_dilut_%d/atrous_conv2" % i, [(d1, h - 4)], dzd2, h - 8, dil=2)
                 self._bwd_data("conv_dilut_%d/atrous_conv2" % i, dzd2, dzd1, h - 4, relu_src=d1, dil=2)
                 if i > 0:
@@ -434,17 +454,19 @@ class UNet:
             if i > 0:
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if self.dilated else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
-        # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised:
-        #   dW0[ci][cj] = sum_{t,co} W1[t][cj][co] * gxc[t][ci][co];  db0[cj] = sum_{t,co} W1[t][cj][co] * db1[co]
-        w1 = self.w["conv_0/conv1/kernel"].reshape(9, 3, -1)
-        dw0 = torch.einsum("tjo,tio->ij", w1, self.gfirst[0].reshape(9, 3, -1))
-        db0 = torch.einsum("tjo,o->j", w1, self.g["conv_0/conv1/bias"])
+        # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
+        #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
+        def first_grads(kname, gx):
+            w1 = self.w[kname].reshape(9, 3, -1)
+            gxc = gx[:, :9, :].reshape(9, 3, 3, -1)
+            return torch.einsum("tjo,tijo->ij", w1, gxc), torch.einsum("tjo,tjo->j", w1, gx[:, 9:, :])
+        dw0, db0 = first_grads("conv_0/conv1/kernel", self.gfirst[0])
         if self.dilated and L > 1:
-            wd = self.w["conv_dilut_0/atrous_conv1/kernel"].reshape(9, 3, -1)
-            dw0 = dw0 + torch.einsum("tjo,tio->ij", wd, self.gfirst[1].reshape(9, 3, -1))
-            db0 = db0 + torch.einsum("tjo,o->j", wd, self.g["conv_dilut_0/atrous_conv1/bias"])
-        self.g["color_space_adjust/kernel"].copy_(dw0.view(1, 1, 3, 3))
-        self.g["color_space_adjust/bias"].copy_(db0)
+            dwd, dbd = first_grads("conv_dilut_0/atrous_conv1/kernel", self.gfirst[1])
+            dw0, db0 = dw0 + dwd, db0 + dbd
+        inv_keep = float(np.float32(1.0) / np.float32(keep))
+        self.g["color_space_adjust/kernel"].copy_((dw0 * inv_keep).view(1, 1, 3, 3))
+        self.g["color_space_adjust/bias"].copy_(db0 * inv_keep)
 
     # ------------------------------------------------------------------ optimizer
     def learning_rate(self, lr0):
@@ -466,9 +488,10 @@ def forward(X, num_layers, root_size, dilated_layers, dropout_keep=None, params=
     """Drop-in for the reference's unet.forward (unet.py:12): X [B,S,S,3] float32 in [0,1] -> logits [B,P,P,2].
 
     The reference builds a TF graph and creates its variables on first use; here the variables live in a cached UNet
-    keyed by the static shapes (pass `params` -- a dict of TF-named numpy arrays -- to set them). dropout_keep must be
-    None or 1.0 (the predict path / the final model); see DESIGN.md for dropout."""
-    assert dropout_keep is None or float(dropout_keep) == 1.0, "HIP path implements dropout_keep == 1.0 (identity) only"
+    keyed by the static shapes (pass `params` -- a dict of TF-named numpy arrays -- to set them). dropout_keep = None or
+    1.0: no dropout (unet.py:29: `if dropout_keep is not None`); < 1: tf.nn.dropout at the 2L-1 sites with counter-based
+    masks."""
+    keep = 1.0 if dropout_keep is None else float(dropout_keep)
     X = torch.as_tensor(X)
     B, S = X.shape[0], X.shape[1]
     assert X.shape[2] == S and X.shape[3] == NUM_CHANNELS
@@ -481,5 +504,5 @@ def forward(X, num_layers, root_size, dilated_layers, dropout_keep=None, params=
     elif params is not None:
         m.load_state_dict(params)
     m.x.copy_(X.to(m.device, torch.float32))
-    m.forward_device(want_logits=True)
+    m.forward_device(want_logits=True, keep=keep)
     return m.logits

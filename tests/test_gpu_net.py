@@ -37,11 +37,12 @@ def _setup(L, root, P, B, dilated, seed=3):
     return S, X, labels, params
 
 
-def _run_hip(L, root, P, B, dilated, X, labels, params):
-    m = UNet(L, root, dilated, B, P, params=params, training=True)
+def _run_hip(L, root, P, B, dilated, X, labels, params, keep=1.0, seed=2017, step=0):
+    m = UNet(L, root, dilated, B, P, params=params, training=True, seed=seed)
+    m.global_step = step
     m.x.copy_(torch.from_numpy(X))
     m.labels.copy_(torch.from_numpy(labels))
-    m.forward_device()
+    m.forward_device(keep=keep)
     m.backward_device(1.0 / (B * P * P))
     torch.cuda.synchronize()
     loss = float(m.loss_sum.item()) / (B * P * P)
@@ -91,6 +92,24 @@ def test_forward_backward_parity(L, root, P, B, dilated):
     w1 = _check(loss, prob, grads, emu, 4e-3, 2e-3, 2e-2, "vs bf16-emulating oracle", noise, 1.0)
     w2 = _check(loss, prob, grads, f32, 3e-2, 1e-2, 1e-1, "vs float32 oracle", noise, 1.5)
     print("worst grad rel err: emu %s %.2e | f32 %s %.2e" % (w1[0], w1[1], w2[0], w2[1]))
+
+
+@pytest.mark.parametrize("L,root,P,B,dilated,keep", [(3, 16, 20, 2, False, 0.8), (3, 32, 36, 1, True, 0.8), (4, 16, 28, 2, True, 0.5)])
+def test_forward_backward_parity_with_dropout(L, root, P, B, dilated, keep):
+    """tf.nn.dropout at all 2L-1 sites (unet.py:29-30,64-65) with the counter-based masks the oracle restates bit for bit:
+    same tolerances as without dropout; a different step must give different masks"""
+    S, X, labels, params = _setup(L, root, P, B, dilated, seed=5)
+    seed, step = 77, 12
+    m, loss, prob, grads = _run_hip(L, root, P, B, dilated, X, labels, params, keep=keep, seed=seed, step=step)
+    emu = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=True, keep=keep, seed=seed, step=step)
+    f32 = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=False, keep=keep, seed=seed, step=step)
+    noise = _rel_errs(emu[2], f32[2])
+    _check(loss, prob, grads, emu, 4e-3, 2e-3, 2e-2, "dropout vs bf16-emulating oracle", noise, 1.0)
+    _check(loss, prob, grads, f32, 3e-2, 1e-2, 1e-1, "dropout vs float32 oracle", noise, 1.5)
+    nodrop = U.loss_and_grads(params, X, labels, L, root, dilated, emulate_bf16=True)
+    assert np.abs(prob - nodrop[1]).max() > 1e-3, "dropout had no effect"
+    _, _, prob2, _ = _run_hip(L, root, P, B, dilated, X, labels, params, keep=keep, seed=seed, step=step + 1)
+    assert np.abs(prob - prob2).max() > 1e-4, "masks must change from step to step"
 
 
 def test_train_steps_match_oracle():

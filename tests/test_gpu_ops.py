@@ -167,9 +167,10 @@ def test_conv2d_bwd_weight_cropped_sources():
 
 
 # ------------------------------------------------------------------------------------------- first layer
-@pytest.mark.parametrize("dil", [1, 2])
-def test_color_adjust_and_first_conv(dil):
+@pytest.mark.parametrize("dil,keep", [(1, 1.0), (2, 1.0), (1, 0.8)])
+def test_color_adjust_and_first_conv(dil, keep):
     rng = np.random.RandomState(11 + dil)
+    key = 0xC0FFEE11
     N, H, W, Cout = 2, 29, 35, 64
     x = rng.rand(N, H, W, 3).astype(np.float32)
     w0 = _rand(rng, 3, 3, scale=0.5)
@@ -178,12 +179,18 @@ def test_color_adjust_and_first_conv(dil):
     b1 = _rand(rng, Cout, scale=0.1)
     in16 = torch.zeros((N, H, W, 16), dtype=torch.bfloat16, device=hu.DEV)
     xd_, w0d, b0d, w1d, b1d = hu.dev_f32(x), hu.dev_f32(w0), hu.dev_f32(b0), hu.dev_f32(w1), hu.dev_f32(b1)  # keep alive
-    call("rsu_color_adjust_fwd", hu.ptr(xd_), hu.ptr(w0d), hu.ptr(b0d), hu.ptr(in16), N * H * W, hu.stream())
+    call("rsu_color_adjust_fwd", hu.ptr(xd_), hu.ptr(w0d), hu.ptr(b0d), hu.ptr(in16), N * H * W, keep, key, hu.stream())
     got16 = hu.host(in16)
-    net0 = U.conv1x1_fwd(x, w0, b0, sub=0.5)
-    hu.assert_bf16_close(got16[..., 0:3], net0, "color_adjust net0")
-    hu.assert_bf16_close(got16[..., 4:7], x - 0.5, "color_adjust xc")
-    assert not got16[..., 3].any() and not got16[..., 7:].any()
+    m = U.dropout_mask((N, H, W, 3), keep, key) if keep < 1.0 else np.ones((N, H, W, 3), np.float32)
+    if keep < 1.0:
+        assert 0.7 < m.mean() < 0.9
+    net0 = U.conv1x1_fwd(x, w0, b0, sub=0.5) * m * (np.float32(1) / np.float32(keep))
+    hu.assert_bf16_close(got16[..., 0:3], net0, "color_adjust net0 (dropout keep=%g)" % keep)
+    for ci in range(3):
+        for cj in range(3):
+            hu.assert_bf16_close(got16[..., 4 + 3 * ci + cj], (x[..., ci] - 0.5) * m[..., cj], "color_adjust xc*m")
+    np.testing.assert_array_equal(got16[..., 13:16], m)
+    assert not got16[..., 3].any()
     Ho, Wo = H - 2 * dil, W - 2 * dil
     y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
     pk1 = torch.zeros(lib().rsu_packed_first_bytes(Cout) // 2, dtype=torch.bfloat16, device=hu.DEV)
@@ -194,14 +201,15 @@ def test_color_adjust_and_first_conv(dil):
     # weight gradients (MFMA narrow wgrad over the 16-channel tensor)
     dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
     dw1 = torch.zeros((3, 3, 3, Cout), dtype=torch.float32, device=hu.DEV)
-    gxc = torch.zeros((3, 3, 3, Cout), dtype=torch.float32, device=hu.DEV)
+    gx = torch.zeros((9, 12, Cout), dtype=torch.float32, device=hu.DEV)
     ws = torch.zeros(lib().rsu_conv_first_bwd_ws_floats(Cout), dtype=torch.float32, device=hu.DEV)
     dzd = hu.dev_bf16(dz)
     dbf = torch.zeros(Cout, dtype=torch.float32, device=hu.DEV)
-    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gxc), hu.ptr(dbf), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
+    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gx), hu.ptr(dbf), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
     hu.assert_f32_close(hu.host(dbf), dz.reshape(-1, Cout).astype(np.float64).sum(0), "conv_first db")
     hu.assert_f32_close(hu.host(dw1), U.conv2d_bwd_weight(got16[..., 0:3], dz, dil=dil)[0], "conv_first dW")
-    hu.assert_f32_close(hu.host(gxc), U.conv2d_bwd_weight(got16[..., 4:7], dz, dil=dil)[0], "conv_first gxc")
+    ref_gx = U.conv2d_bwd_weight(got16[..., 4:16], dz, dil=dil)[0].reshape(9, 12, Cout)  # rows: 9 masked (x-0.5) products, 3 mask sums
+    hu.assert_f32_close(hu.host(gx), ref_gx, "conv_first gx")
 
 
 # ------------------------------------------------------------------------------------------- pool
@@ -212,20 +220,25 @@ def test_maxpool_fwd_and_junction_bwd(N, H, W, C):
     x[0, :4, :4, :] = x[0, 0, 0, :]  # force ties (incl. zeros) in a corner
     xd = hu.dev_bf16(x)
     y = torch.zeros((N, H // 2, W // 2, C), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_maxpool2x2_fwd", hu.ptr(xd), hu.ptr(y), N, H, W, C, hu.stream())
+    call("rsu_maxpool2x2_fwd", hu.ptr(xd), hu.ptr(y), N, H, W, C, 1.0, 0, hu.stream())
     np.testing.assert_array_equal(hu.host(y), U.maxpool_fwd(x))
+    # with the next level's dropout fused (unet.py:29-30)
+    keep, key = 0.8, 0x1234ABCD
+    mk = U.dropout_mask(y.shape, keep, key) * (np.float32(1) / np.float32(keep))
+    call("rsu_maxpool2x2_fwd", hu.ptr(xd), hu.ptr(y), N, H, W, C, keep, key, hu.stream())
+    np.testing.assert_array_equal(hu.host(y), hu.q(U.maxpool_fwd(x) * mk))
     Hs, Ws = H - 4, W - 6
     dpool = hu.q(_rand(rng, N, H // 2, W // 2, C))
     dskip = hu.q(_rand(rng, N, Hs, Ws, C))
     dpd, dsd = hu.dev_bf16(dpool), hu.dev_bf16(dskip)
-    for use_pool, use_skip in [(1, 1), (1, 0), (0, 1)]:
+    for use_pool, use_skip, kp in [(1, 1, 1.0), (1, 0, 1.0), (0, 1, 1.0), (1, 1, keep)]:
         dz = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
         call("rsu_pool_skip_relu_bwd", hu.ptr(xd), hu.ptr(dpd) if use_pool else None,
-             hu.ptr(dsd) if use_skip else None, hu.ptr(dz), N, H, W, C, Hs, Ws, hu.stream())
+             hu.ptr(dsd) if use_skip else None, hu.ptr(dz), N, H, W, C, Hs, Ws, kp, key, hu.stream())
         g = np.zeros_like(x)
         if use_pool:
             xe = x[:, :H // 2 * 2, :W // 2 * 2]
-            g[:, :H // 2 * 2, :W // 2 * 2] += U.maxpool_bwd(xe, dpool)
+            g[:, :H // 2 * 2, :W // 2 * 2] += U.maxpool_bwd(xe, dpool * mk if kp < 1.0 else dpool)
         if use_skip:
             g += U.center_pad_like(dskip, x.shape)
         ref = U.relu_bwd(x, g)
@@ -254,9 +267,18 @@ def test_convT(N, H, W, Cin, Cout):
     dy = hu.q(_rand(rng, N, 2 * H, 2 * W, Cout, scale=0.1))
     dyd = hu.dev_bf16(dy)
     dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xd), N, H, W, Cin, Cout, hu.stream())
+    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xd), 1.0, N, H, W, Cin, Cout, hu.stream())
     rdx, rdK, rdb = U.convT_bwd(x, hu.q(K), dy)
     hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx), "convT bwd_data")
+    # dropout in front of the transposed conv (unet.py:64-65): forward kernel + backward fused as (mask source, scale)
+    keep, key = 0.8, 0x5EED0001
+    inv = np.float32(1) / np.float32(keep)
+    xdrop = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_dropout_fwd", hu.ptr(xd), hu.ptr(xdrop), x.size, keep, key, hu.stream())
+    m = U.dropout_mask(x.shape, keep, key)
+    np.testing.assert_array_equal(hu.host(xdrop), hu.q(x * m * inv))
+    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xdrop), float(inv), N, H, W, Cin, Cout, hu.stream())
+    hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx * m * inv), "convT bwd_data with dropout")
     dK = torch.full((2, 2, Cout, Cin), float("nan"), dtype=torch.float32, device=hu.DEV)
     ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(Cin, Cout), dtype=torch.float32, device=hu.DEV)
     dbT = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)

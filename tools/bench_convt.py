@@ -47,7 +47,7 @@ def main():
         ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(cin, cout), device=DEV)
         fl = 2.0 * B * (2 * h) * (2 * h) * cin * cout
         t0 = timeit(lambda: call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, st))
-        t1 = timeit(lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), B, h, h, cin, cout, st))
+        t1 = timeit(lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, st))
         t2 = timeit(lambda: call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), None, ptr(ws), B, h, h, cin, cout, st))
         mb = (x.numel() + dy.numel()) * 2 / 1e6
         print("up_conv_%d H%4d C%4d->%4d %6.1f GF %6.1f MB | fwd %5.0fus %4.0fTF | bwd %5.0fus %4.0fTF | wg %5.0fus %4.0fTF" %

@@ -25,7 +25,7 @@ for _ in range(5):
     if op == "fwd":
         call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, st)
     elif op == "bwd":
-        call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), B, h, h, cin, cout, st)
+        call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, st)
     else:
         call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), None, ptr(ws), B, h, h, cin, cout, st)
 torch.cuda.synchronize()
