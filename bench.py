@@ -9,6 +9,7 @@ accumulate, 4 patches per GPU (weak scaling: the global batch is 4*N), synthetic
 X ~ U[0,1), labels ~ Bernoulli(0.2), Glorot-uniform weights, lr 0.01, momentum 0.9, dropout_keep 1.0. A step is
 session.run([train, loss, predictions]) of the reference (tf_aerial_images.py:241-244): forward, loss, full backward,
 gradient all-reduce over RCCL when N > 1, Momentum update of every live variable and the bf16 re-pack of the weights.
+The weight-gradient launches of a step run on a second HIP stream beside the backward-data launches (RSU_WGRAD_STREAM=0: one stream).
 Inputs are resident in HBM before the timed region (the reference feeds host numpy arrays; the PCIe-inclusive figure is
 discussed in DESIGN.md and is never `value`).
 
@@ -159,11 +160,15 @@ def main():
     loss = float(m.loss_sum.item()) * m._inv_count * 1.0
 
     # ---- instrumented pass (HIP events on the launch stream around every 3x3-conv MFMA launch)
+    # (single stream here: in the timed region the weight-gradient launches run on a second stream and share the chip with the
+    # backward-data launches, which stretches every launch it overlaps; the roofline figure wants each kernel's own duration)
     nprof = 3
     m.prof = []
+    wstream, m.wstream = m.wstream, None
     for _ in range(nprof):
         run_step(m, bucketer, lr, mu)
     torch.cuda.synchronize()
+    m.wstream = wstream
     agg = {}
     for tag, fl, e0, e1 in m.prof:
         a = agg.setdefault(tag, [0.0, 0.0, 0])

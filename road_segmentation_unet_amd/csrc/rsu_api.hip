@@ -337,7 +337,9 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         double ovh = 4096.0 * 1152.0 / (double)(ktot > 0 ? ktot : 1152);
         if (ovh < 4096.0) ovh = 4096.0;
         if (ovh > 65536.0) ovh = 65536.0;
-        const double cost = (double)rounds * ((double)ci.TM * ci.TN + ovh);
+        // RSU_PLAN_FRAC=1 (A/B): price a fractional last round, as if another stream's kernel filled the idle CUs
+        const double nrounds = env_int("RSU_PLAN_FRAC", 0) ? (double)ntile_m / (double)workers : (double)rounds;
+        const double cost = nrounds * ((double)ci.TM * ci.TN + ovh);
         if (cost < best_cost) {
             best_cost = cost;
             best.cfg = cfg;

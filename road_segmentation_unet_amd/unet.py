@@ -8,6 +8,7 @@ arithmetic kernel on the path is a hand-written HIP kernel reached through librs
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -100,6 +101,9 @@ class UNet:
         self.training = training
         self.keep = 1.0        # dropout keep probability of the forward pass in flight (set by forward_device)
         self.dropout_seed = int(seed) if seed is not None else 0
+        self.wstream = None    # second stream for the weight-gradient launches (see _Side)
+        if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
+            self.wstream = torch.cuda.Stream(device=self.device)
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
@@ -288,7 +292,33 @@ class UNet:
 
     def _grads_ready(self, name):
         if self.on_grads is not None:
+            self._join_side()
             self.on_grads(self._slices[name][0])
+
+    # Weight-gradient launches can go to a second stream: they only READ what the main stream produced (dz, activations) and
+    # write gradients nobody reads before the optimizer. Two persistent kernels then share the chip and each fills the other's
+    # poorly occupied last round of tiles. RSU_WGRAD_STREAM=0 keeps everything on one stream.
+    class _Side:
+        def __init__(self, net):
+            self.net, self.ctx = net, None
+
+        def __enter__(self):
+            n = self.net
+            if n.wstream is None:
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(n.device))
+            n.wstream.wait_event(ev)
+            self.ctx = torch.cuda.stream(n.wstream)
+            self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+
+    def _join_side(self):
+        if self.wstream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.wstream)
 
     def _conv(self, name, srcs, hin, out, dil=1):
         arr = (RsuSrc * len(srcs))(*srcs)
@@ -360,16 +390,17 @@ class UNet:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, name, srcs_t, dz, hout, dil=1):
         """dW (HWIO rows per source) + db of conv `name`; srcs_t = list of (tensor, window size)"""
-        st = self._stream()
         cout = dz.shape[3]
         cin_total = self.w[name + "/kernel"].shape[2]
         off = 0
-        for t, win in srcs_t:
-            s = _src(t, win, win)
-            db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
-            self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
-                        _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
-            off += t.shape[3]
+        with UNet._Side(self):
+            st = self._stream()
+            for t, win in srcs_t:
+                s = _src(t, win, win)
+                db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
+                self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
+                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
+                off += t.shape[3]
 
     def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
         """Conv2DBackpropInput towards concat source `src_index` of conv `name` (its own weight pack)"""
@@ -411,8 +442,9 @@ class UNet:
             if keep < 1.0:  # the transposed conv read the dropped tensor; (dropped > 0) = ReLU mask AND keep mask
                 upin = a["drop_%d" % i]
             hh = h // 2
-            call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
-                 _ptr(self.ws), B, hh, hh, upin.shape[3], nf, st)
+            with UNet._Side(self):
+                call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
+                     _ptr(self.ws), B, hh, hh, upin.shape[3], nf, self._stream())
             call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), float(np.float32(1.0) / np.float32(keep)), B, hh, hh,
                  upin.shape[3], nf, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
@@ -434,8 +466,9 @@ class UNet:
                 self._wgrad("conv_%d/conv1" % i, [(pin, h)], dz1, h - 2)
                 self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
             else:
-                call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
-                     _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B, h, h, nf, 1, st)
+                with UNet._Side(self):
+                    call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
+                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B, h, h, nf, 1, self._stream())
             if self.dilated and i < L - 1:
                 d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
@@ -449,11 +482,13 @@ class UNet:
                     self._wgrad("conv_dilut_%d/atrous_conv1" % i, [(pin, h)], dzd1, h - 4, dil=2)
                     self._bwd_data("conv_dilut_%d/atrous_conv1" % i, dzd1, g["pool_%d" % (i - 1)], h, accumulate=1, dil=2)
                 else:
-                    call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
-                         _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, st)
+                    with UNet._Side(self):
+                        call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
+                             _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, self._stream())
             if i > 0:
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if self.dilated else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
+        self._join_side()
         # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
         #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
         def first_grads(kname, gx):
