@@ -650,6 +650,19 @@ hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void*
     hipLaunchKernelGGL(k_color_adjust, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, x, w, b, (bf16_t*)out16, npix, keep, key);
     return hipGetLastError();
 }
+__global__ void k_scale_bf16(bf16_t* __restrict__ x, long n8, float s) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(*(const u32x4*)(x + 8 * t), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= s;
+        *(u32x4*)(x + 8 * t) = pack8(v);
+    }
+}
+hipError_t ew_scale_bf16(void* x, long n, float s, hipStream_t st) {
+    hipLaunchKernelGGL(k_scale_bf16, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (bf16_t*)x, n / 8, s);
+    return hipGetLastError();
+}
 hipError_t ew_dropout(const void* x, void* y, long n, float keep, unsigned key, hipStream_t st) {
     hipLaunchKernelGGL(k_dropout, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / 8, keep, key);
     return hipGetLastError();

@@ -38,7 +38,6 @@ struct IgFwdParams {
     int lsw;              // log2(g.SW) for the aligned-tile kernels (igemm_fwd2)
     int dbg;              // developer A/B switch (RSU_FWD_DBG): bit 0 = skip weight staging, bit 1 = skip halo staging (timing only)
     TileGeo g;
-    float oscale;         // factor applied to the result before mask / accumulate (1/keep of a dropout upstream of a transposed conv)
 };
 
 // config ids (see igemm_fwd.hip for the tile shapes)

@@ -194,12 +194,6 @@ igemm_fwd_kernel(const IgFwdParams p) {
                 v[i] = acc[2 * pp][pt][i] + bv[i];
                 v[4 + i] = acc[2 * pp + 1][pt][i] + bv[4 + i];
             }
-            if (p.oscale != 1.f) {  // 1/keep of a dropout upstream of a transposed conv; through a VGPR and plain v_mul_f32 (igemm_fwd2.hip)
-                float os = p.oscale;
-                asm volatile("" : "+v"(os));
-#pragma unroll
-                for (int i = 0; i < 8; ++i) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(os));
-            }
             if (p.mask_src) {
                 const u32x4 mk = *(const u32x4*)(p.mask_src + idx);
 #pragma unroll

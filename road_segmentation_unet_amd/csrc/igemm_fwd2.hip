@@ -245,8 +245,6 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
                 const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
                 voffs[e] = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
-                mk4[e] = u32x4{0u, 0u, 0u, 0u};
-                ob4[e] = u32x4{0u, 0u, 0u, 0u};
                 if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
                 if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
             }
@@ -258,12 +256,6 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 for (int i = 0; i < 4; ++i) {
                     v[i] = acc[2 * pp][pt][i];
                     v[4 + i] = acc[2 * pp + 1][pt][i];
-                }
-                if (p.oscale != 1.f) {  // (the scale goes through a VGPR: the packed multiply by the scalar argument came out wrong)
-                    float os = p.oscale;
-                    asm volatile("" : "+v"(os));
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(os));
                 }
                 if (p.mask_src) {
 #pragma unroll
@@ -398,7 +390,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tl & 1][ct], fb[tl & 1][pt], acc[ct][pt], 0, 0, 0);
+                            mfma_bf16_inplace(acc[ct][pt], fa[tl & 1][ct], fb[tl & 1][pt]);
                     // LDS-DMA bookkeeping for the stages ahead, placed BEHIND a block of MFMAs and staggered between the two
                     // waves of a SIMD (waves w and w+4): while one does scalar address work its partner feeds the matrix pipe
                     if (TPS == 1 || NW == 4) {
@@ -422,6 +414,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             }
             ca_slot = ca_slot == NAB - 1 ? 0 : ca_slot + 1;
         }
+        mfma_results_fence();
         epilogue(ctile, acc);
     }
 }

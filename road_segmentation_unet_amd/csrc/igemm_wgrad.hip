@@ -247,28 +247,31 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             for (int ct = 0; ct < CFT; ++ct)
 #pragma unroll
                 for (int st = 0; st < CST; ++st)
-                    acc[tap][ct][st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & (FB - 1)][ct], sv[step & 1][st], acc[tap][ct][st], 0, 0, 0);
+                    mfma_bf16_inplace(acc[tap][ct][st], fa[ks & (FB - 1)][ct], sv[step & 1][st]);  // vDst == SrcC by construction (rsu_common.h)
             if (do_sbias) {
                 unsigned o1 = 0x3f803f80u;
                 asm volatile("" : "+v"(o1));
                 const u32x4 o4 = {o1, o1, o1, o1};
-                const bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                asm volatile("s_nop 3" : "+v"(ones));  // VALU-written operand -> (asm) MFMA read: the hazard recogniser cannot see it
 #pragma unroll
-                for (int st = 0; st < CST; ++st) accs[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, sv[step & 1][st], accs[st], 0, 0, 0);
+                for (int st = 0; st < CST; ++st) mfma_bf16_inplace(accs[st], ones, sv[step & 1][st]);
             }
             if (tap == 0 && do_bias) {
                 // the all-ones operand is re-materialised here (four v_mov per k-step) instead of living in four VGPRs
                 unsigned o1 = 0x3f803f80u;
                 asm volatile("" : "+v"(o1));
                 const u32x4 o4 = {o1, o1, o1, o1};
-                const bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                asm volatile("s_nop 3" : "+v"(ones));  // VALU-written operand -> (asm) MFMA read: the hazard recogniser cannot see it
 #pragma unroll
                 for (int ct = 0; ct < CFT; ++ct)
-                    accb[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & (FB - 1)][ct], ones, accb[ct], 0, 0, 0);
+                    mfma_bf16_inplace(accb[ct], fa[ks & (FB - 1)][ct], ones);
             }
         }
         buf = buf + 1 == nbuf ? 0 : buf + 1;
     }
+    mfma_results_fence();
     __syncthreads();  // the staging buffers are dead from here on
 
     // ---- KG = 2: wave group 1 hands its partial sums to group 0 through LDS (the staging buffers are dead by now; the launch

@@ -355,8 +355,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
-                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st,
-                   float oscale = 1.f) {
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
     const int kh = ntap / kw;
     const long out_bytes = (long)N * oH * oW * outC * 2;
     bool gen2 = env_int("RSU_FWD_GEN", 2) == 2 && out_bytes < 0x7ffffff0L;
@@ -396,7 +395,6 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.dil = dil; p.stride = stride; p.pad = pad;
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
-    p.oscale = oscale;
     if (use2) {
         p.ncob = pl2.ncob;
         p.g = pl2.g;
@@ -478,8 +476,13 @@ extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, voi
     if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2 || !(out_scale > 0.f)) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
-    return run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0, H, W,
-                   1, 1, 0, 0, (hipStream_t)stream, out_scale);
+    const int rc = run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0,
+                           H, W, 1, 1, 0, 0, (hipStream_t)stream);
+    if (rc != RSU_OK || out_scale == 1.f) return rc;
+    // 1/keep of a dropout in front of the transposed conv: a separate pass over the (small) gradient tensor, training with
+    // dropout only -- the MFMA kernel's epilogue is left alone (see DESIGN.md section 4 on what scaling there cost)
+    HIP_CHECK_RET(ew_scale_bf16(dx, (long)N * H * W * Cin, out_scale, (hipStream_t)stream));
+    return RSU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

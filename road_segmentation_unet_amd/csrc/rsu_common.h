@@ -29,6 +29,19 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, r);
 }
 
+// ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand).
+// Why not the builtin: under register pressure hipcc writes the result to a fresh tuple and re-uses the SrcC registers a few
+// instructions later (DMA addresses, selects). Its WAR distance is sized for one wave per SIMD; with two waves per SIMD (all
+// kernels here) an MFMA can sit behind the partner wave's MFMA before it starts reading SrcC, the later write lands first, and
+// a quarter of the lanes of one or two accumulator registers come out as address bits -- intermittently, only in the shapes
+// with 64 accumulator registers. With vDst == SrcC no register is freed by an MFMA, so nothing can be written over it early.
+// Consequences of the asm being opaque to the hazard recogniser: the caller keeps dependent MFMAs on one accumulator at least
+// 4 MFMAs apart (they are 16 apart here) and idles 32 cycles before the first VALU read of the results (mfma_results_fence).
+__device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_results_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 // ---- async global -> LDS copy, 16 bytes per lane (LDS destination = wave-uniform base + lane*16)
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -1,0 +1,71 @@
+"""-m gpu: every tile shape of the second-generation conv kernel, forced (RSU_FWD2_CFG), on shapes big enough to run several
+tiles per workgroup and the full-size pipeline states -- the planner alone never picks the large shapes on small test inputs.
+Each case runs three times: the failures this guards against (lost accumulator lanes under register pressure)
+were intermittent."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as U  # noqa: E402
+from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
+from tests import hiputil as hu  # noqa: E402
+
+
+@pytest.fixture(params=[0, 1, 2, 3])
+def forced_cfg(request):
+    old = os.environ.get("RSU_FWD2_CFG")
+    os.environ["RSU_FWD2_CFG"] = str(request.param)
+    yield request.param
+    if old is None:
+        os.environ.pop("RSU_FWD2_CFG", None)
+    else:
+        os.environ["RSU_FWD2_CFG"] = old
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 150, 140, 64, 64), (1, 70, 75, 64, 192), (2, 60, 60, 16, 64)])
+def test_conv3x3_fwd_and_bwd_data_every_shape(forced_cfg, N, H, W, Cin, Cout):
+    rng = np.random.RandomState(H + Cout)
+    x = hu.q(_rand(rng, N, H, W, Cin))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    xd, wp, bd = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b)
+    ref = U.conv2d_fwd(x, hu.q(w), b)
+    s = (RsuSrc * 1)(hu.src_of(xd, H, W))
+    for rep in range(3):
+        y = torch.full((N, H - 2, W - 2, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, 1, 1, hu.stream())
+        hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd cfg %d rep %d" % (forced_cfg, rep))
+    if Cin % 32:
+        return
+    dz = hu.q(_rand(rng, N, H - 2, W - 2, Cout, scale=0.1))
+    dzd, wb = hu.dev_bf16(dz), hu.pack_conv_bwd(w, 0, Cin)
+    rdx = U.relu_bwd(x, U.conv2d_bwd_data(dz, hu.q(w), (H, W)))
+    for rep in range(3):
+        dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), hu.ptr(xd), 0, N, H, W, Cin, 0, Cin, Cout, 1, hu.stream())
+        hu.assert_bf16_close(hu.host(dx), rdx, "conv2d_bwd_data cfg %d rep %d" % (forced_cfg, rep))
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 28, 28, 256, 128), (2, 100, 100, 256, 128), (1, 60, 60, 128, 64)])
+def test_convT_fwd_every_shape(forced_cfg, N, H, W, Cin, Cout):
+    rng = np.random.RandomState(Cin + H)
+    x = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
+    K = _rand(rng, 2, 2, Cout, Cin, scale=1.0 / np.sqrt(Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    pf = torch.zeros(4 * lib().rsu_packed_bytes(1, Cout, (ctypes.c_int * 1)(Cin), 1) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    Kd, xd, bd = hu.dev_f32(K), hu.dev_bf16(x), hu.dev_f32(b)
+    call("rsu_pack_convT_fwd", hu.ptr(Kd), hu.ptr(pf), Cin, Cout, hu.stream())
+    ref = U.convT_fwd(x, hu.q(K), b)
+    for rep in range(3):
+        y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        call("rsu_convT2x2_fwd", hu.ptr(xd), hu.ptr(pf), hu.ptr(bd), hu.ptr(y), N, H, W, Cin, Cout, hu.stream())
+        hu.assert_bf16_close(hu.host(y), ref, "convT fwd cfg %d rep %d" % (forced_cfg, rep))

@@ -180,3 +180,60 @@ def test_linearity_property_full_size_layer():
     tol = 2.0 ** -8 * (lhs.abs() + outs[0].abs() + outs[1].abs()) + 1e-3
     assert float(outs[0].abs().max()) > 0.5
     assert bool(((lhs - rhs).abs() <= tol).all())
+
+
+# ------------------------------------------------------------------------------------------- BASELINE config 2 at full size
+C2 = (5, 64, 388)  # num_layers, root_size, patch_size (input 572)
+
+
+def test_c2_full_size_forward_matches_oracle():
+    """config 2 geometry (L=5, root=64, 572 -> 388), one patch: probabilities against the bf16-emulating oracle and the
+    float32 oracle (same tolerances as the small cases)"""
+    L, root, P = C2
+    S, X, labels, params = _setup(L, root, P, 1, False, seed=21)
+    m = UNet(L, root, False, 1, P, params=params, training=False)
+    m.x.copy_(torch.from_numpy(X))
+    m.forward_device()
+    torch.cuda.synchronize()
+    prob = m.prob.cpu().numpy()
+    emu = U.predict_probs(params, X, L, root, False, emulate_bf16=True)
+    f32 = U.predict_probs(params, X, L, root, False, emulate_bf16=False)
+    d_emu, d_f32, noise = np.abs(prob - emu), np.abs(prob - f32), np.abs(emu - f32)
+    print("c2 forward: max|hip-emu| %.2e mean %.2e | max|hip-f32| %.2e | oracle bf16-vs-f32 max %.2e mean %.2e" %
+          (d_emu.max(), d_emu.mean(), d_f32.max(), noise.max(), noise.mean()))
+    # two correct bf16 evaluations differ by rounding-boundary flips (fp32 summation order): a fraction of the oracles' own
+    # bf16-vs-f32 distance, which grows with depth and width (150 k pixels, 23 layers, up to 1024 channels here)
+    assert d_emu.max() <= max(4e-3, 0.6 * noise.max()), (float(d_emu.max()), float(noise.max()))
+    assert d_emu.mean() <= 1e-3
+    assert d_f32.max() <= 3e-2, float(d_f32.max())
+
+
+def test_c2_full_size_step_properties():
+    """size-independent properties of a full config-2 training step (B=2):
+    * bit-exact repeatability (split-K slab order, two-stream schedule): same state + same input -> identical gradients;
+    * batch consistency: a batch of two identical patches has the loss and (up to fp32 summation order) the gradients of one;
+    * dead variables (conv_dilut level L-1 does not exist here) / every live gradient is finite and non-zero."""
+    L, root, P = C2
+    S, X1, lab1, params = _setup(L, root, P, 1, False, seed=22)
+    X2, lab2 = np.concatenate([X1, X1]), np.concatenate([lab1, lab1])
+
+    def run(B, X, lab):
+        m = UNet(L, root, False, B, P, params=params, training=True)
+        m.x.copy_(torch.from_numpy(X))
+        m.labels.copy_(torch.from_numpy(lab))
+        m.forward_device()
+        m.backward_device(1.0 / (B * P * P))
+        torch.cuda.synchronize()
+        return float(m.loss_sum.item()) / (B * P * P), {n: m.g[n].detach().cpu().numpy().copy() for n in m.names}
+
+    la, ga = run(2, X2, lab2)
+    lb, gb = run(2, X2, lab2)
+    assert la == lb
+    for n in ga:
+        np.testing.assert_array_equal(ga[n], gb[n], err_msg=n)
+        assert np.isfinite(ga[n]).all() and np.abs(ga[n]).max() > 0, n
+    l1, g1 = run(1, X1, lab1)
+    assert abs(la - l1) <= 1e-5 * abs(l1)
+    for n in ga:
+        e = np.linalg.norm((ga[n] - g1[n]).astype(np.float64)) / np.linalg.norm(g1[n].astype(np.float64))
+        assert e <= 2e-3, (n, e)
