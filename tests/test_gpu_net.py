@@ -237,3 +237,18 @@ def test_c2_full_size_step_properties():
     for n in ga:
         e = np.linalg.norm((ga[n] - g1[n]).astype(np.float64)) / np.linalg.norm(g1[n].astype(np.float64))
         assert e <= 2e-3, (n, e)
+
+
+def test_c2_full_size_gradients_match_oracle():
+    """config 2 geometry, one patch: loss and EVERY gradient tensor against the bf16-emulating oracle (Frobenius), tolerance =
+    max(2e-2, the oracles' own bf16-vs-f32 distance) as in the small cases. ~30 s of oracle time on the host cores: this is the
+    test that exercises the large tile shapes and multi-tile workgroups of all three MFMA kernels end to end."""
+    L, root, P = C2
+    S, X, labels, params = _setup(L, root, P, 1, False, seed=31)
+    m, loss, prob, grads = _run_hip(L, root, P, 1, False, X, labels, params)
+    emu = U.loss_and_grads(params, X, labels, L, root, False, emulate_bf16=True)
+    f32 = U.loss_and_grads(params, X, labels, L, root, False, emulate_bf16=False)
+    noise = _rel_errs(emu[2], f32[2])
+    assert abs(loss - emu[0]) <= 2e-4 * abs(emu[0]), (loss, emu[0])
+    worst = _check(loss, prob, grads, emu, 1e-2, 2e-3, 2e-2, "c2 full size vs bf16-emulating oracle", noise, 1.0)
+    print("c2 full size: worst gradient rel err %s %.2e" % worst)
