@@ -229,7 +229,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
         constexpr int NS = KSG * NTAP;
         // F fragments are double-buffered across k-steps unless the wave already holds 64 F channels x all k-steps (128x64
         // shape: 16 more VGPRs would spill); then they are fetched at the head of each k-step and the partner wave covers the wait
-        constexpr int FB = (KG == 1 && CFT >= 4) ? 1 : 2;
+        constexpr int FB = 2;
         bf16x8 fa[FB][CFT], sv[2][CST];
         load_F(0, fa[0]);
         load_S(0, 0, sv[0]);
