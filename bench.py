@@ -136,6 +136,7 @@ def main():
     bucketer = None
     if world > 1:
         bucketer = GradBucketer(m.flat_g, m.n_live)
+        bucketer.extra_streams = [m.wstream]
         m.on_grads = bucketer.ready
     lr, mu = 0.01, 0.9
 

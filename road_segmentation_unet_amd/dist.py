@@ -41,6 +41,7 @@ class GradBucketer:
             import os
             overlap = os.environ.get("RSU_DP_OVERLAP", "1") != "0"
         self.overlap = overlap
+        self.extra_streams = []   # producer streams besides the current one (the network's weight-gradient stream)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
@@ -55,10 +56,11 @@ class GradBucketer:
             return
         view = self.flat[lo:hi]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.flat.device))
+            for prod in [torch.cuda.current_stream(self.flat.device)] + [s for s in self.extra_streams if s is not None]:
+                ev = torch.cuda.Event()
+                ev.record(prod)
+                self.comm_stream.wait_event(ev)  # only the communication stream waits: the producers keep running
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
                 self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -99,6 +99,7 @@ class ConvolutionalModel:
         self._bucketer = None
         if self.world > 1:
             self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
+            self._bucketer.extra_streams = [self.net.wstream]
             self.net.on_grads = self._bucketer.ready
             # identical initial weights on every rank (the reference has one copy; ranks must start from the same point)
             dist.broadcast(self.net.flat_w, 0)

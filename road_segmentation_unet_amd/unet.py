@@ -291,8 +291,7 @@ class UNet:
         self.prof.append((tag, flops, e0, e1))
 
     def _grads_ready(self, name):
-        if self.on_grads is not None:
-            self._join_side()
+        if self.on_grads is not None:  # (dist.GradBucketer waits for the weight-gradient stream itself: extra_streams)
             self.on_grads(self._slices[name][0])
 
     # Weight-gradient launches can go to a second stream: they only READ what the main stream produced (dz, activations) and
