@@ -73,62 +73,8 @@ __global__ void k_dropout(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// first 3x3 conv (Cin = 3): fp32 VALU, 8 output channels x 4 pixels per thread, weights in LDS
+// level-0 conv1 gradients: rows of the 16-channel wgrad result -> dW1 / colour-adjust helper sums
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_conv_first_fwd(const bf16_t* __restrict__ in16, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int N, int H,
-                                                        int W, int Cout, int dil) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ws = (float*)smem;  // [27][Cout]
-    for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) ws[i] = w[i];
-    __syncthreads();
-    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
-    const int ncg = Cout >> 3, nxq = (Wo + 3) >> 2;
-    const long total = (long)N * Ho * nxq * ncg;
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= total) return;
-    const int cg = (int)(tid % ncg);
-    long r = tid / ncg;
-    const int xq = (int)(r % nxq);
-    r /= nxq;
-    const int oy = (int)(r % Ho), n = (int)(r / Ho);
-    const int ox0 = xq * 4, co = cg * 8;
-    float acc[4][8];
-#pragma unroll
-    for (int px = 0; px < 4; ++px)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[px][i] = bias ? bias[co + i] : 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const bf16_t* row = in16 + ((long)(n * H + oy + ky * dil) * W) * 16;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            float wv[3][8];
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) wv[ci][i] = ws[((ky * 3 + kx) * 3 + ci) * Cout + co + i];
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                int ix = ox0 + px + kx * dil;
-                if (ix > W - 1) ix = W - 1;  // only reached by pixels that are not stored
-                const u32x2 v = *(const u32x2*)(row + (long)ix * 16);
-                const float x0 = bf_lo(v[0]), x1 = bf_hi(v[0]), x2 = bf_lo(v[1]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[px][i] = fmaf(x2, wv[2][i], fmaf(x1, wv[1][i], fmaf(x0, wv[0][i], acc[px][i])));
-            }
-        }
-    }
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-        if (ox0 + px >= Wo) break;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[px][i] = fmaxf(acc[px][i], 0.f);
-        *(u32x4*)(y + ((long)(n * Ho + oy) * Wo + ox0 + px) * Cout + co) = pack8(acc[px]);
-    }
-}
-
-// rows 0..2 / 4..6 of the [9][16][Cout] narrow weight-gradient block -> dw1 / gxc [9][3][Cout]
 __global__ void k_scatter_first_grads(const float* __restrict__ tmp, float* __restrict__ dw1, float* __restrict__ gx, int Cout) {
     // tmp [9][16][Cout] -> dw1 [9][3][Cout] (rows 0..2) and gx [9][12][Cout] (rows 4..15: 9 masked (x-0.5) products, 3 mask sums)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -665,14 +611,6 @@ hipError_t ew_scale_bf16(void* x, long n, float s, hipStream_t st) {
 }
 hipError_t ew_dropout(const void* x, void* y, long n, float keep, unsigned key, hipStream_t st) {
     hipLaunchKernelGGL(k_dropout, dim3(grid_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n / 8, keep, key);
-    return hipGetLastError();
-}
-hipError_t ew_conv_first_fwd(const void* in16, const float* w, const float* b, void* y, int N, int H, int W, int Cout, int dil,
-                             hipStream_t st) {
-    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
-    const long total = (long)N * Ho * ((Wo + 3) / 4) * (Cout / 8);
-    hipLaunchKernelGGL(k_conv_first_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 27 * Cout * sizeof(float), st,
-                       (const bf16_t*)in16, w, b, (bf16_t*)y, N, H, W, Cout, dil);
     return hipGetLastError();
 }
 hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st) {

@@ -309,7 +309,7 @@ static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
 struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
 static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
-                      int force_cfg) {
+                      int force_cfg, bool shared_chip = false) {
     double best_cost = 1e300;
     bool have = false;
     for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
@@ -337,8 +337,9 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         double ovh = 4096.0 * 1152.0 / (double)(ktot > 0 ? ktot : 1152);
         if (ovh < 4096.0) ovh = 4096.0;
         if (ovh > 65536.0) ovh = 65536.0;
-        // RSU_PLAN_FRAC=1 (A/B): price a fractional last round, as if another stream's kernel filled the idle CUs
-        const double nrounds = env_int("RSU_PLAN_FRAC", 0) ? (double)ntile_m / (double)workers : (double)rounds;
+        // shared_chip: the launch runs beside another stream's persistent kernel (backward-data beside the weight gradients), which
+        // fills the idle CUs of a partial last round -- price the rounds fractionally and let the more efficient big tiles win
+        const double nrounds = shared_chip ? (double)ntile_m / (double)workers : (double)rounds;
         const double cost = nrounds * ((double)ci.TM * ci.TN + ovh);
         if (cost < best_cost) {
             best_cost = cost;
@@ -365,7 +366,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     Fwd2Plan pl2;
     int ktot = 0;
     for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * ntap;
-    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, env_int("RSU_FWD2_CFG", -1));
+    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, env_int("RSU_FWD2_CFG", -1), pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0);
     if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
