@@ -230,7 +230,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                                            cob * TN + wco * (CT / 2) * 32) * 2);
         // NST stores in batches of four: the mask / accumulate loads of a batch are requested together (one memory latency per
         // batch instead of one per store); larger batches would need more than the 16-32 VGPRs that are free here
-        constexpr int EB = 4;
+        constexpr int EB = NST % 4 == 0 ? 4 : 2;
         static_assert(NST % EB == 0, "epilogue batches");
 #pragma unroll
         for (int b0 = 0; b0 < NST; b0 += EB) {
@@ -439,6 +439,15 @@ template <> struct Fwd2Cfg<IGF2_CFG_64x256> {
     static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2;
     static constexpr int na(int ntap) { return ntap == 1 ? 2 : 4; }
 };
+// five pixel fragments per wave (80 accumulator registers): a fifth fewer weight pieces and LDS reads per MFMA than 128x256
+template <> struct Fwd2Cfg<IGF2_CFG_128x320> {
+    static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 5;
+    static constexpr int na(int ntap) { return ntap == 1 ? 3 : 5; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_64x640> {
+    static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 5;
+    static constexpr int na(int ntap) { return ntap == 1 ? 5 : 7; }
+};
 template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> {
     static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8;
     static constexpr int na(int) { return 7; }
@@ -464,6 +473,8 @@ IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
         CASE(IGF2_CFG_64x256)
         CASE(IGF2_CFG_128x256_W4)
         CASE(IGF2_CFG_64x512_W4)
+        CASE(IGF2_CFG_128x320)
+        CASE(IGF2_CFG_64x640)
 #undef CASE
     }
     return IgFwdCfgInfo{0, 0, 0};
@@ -477,6 +488,8 @@ int igemm_fwd2_max_pieces(int cfg, int ntap) {
         CASE(IGF2_CFG_64x256)
         CASE(IGF2_CFG_128x256_W4)
         CASE(IGF2_CFG_64x512_W4)
+        CASE(IGF2_CFG_128x320)
+        CASE(IGF2_CFG_64x640)
 #undef CASE
     }
     return 0;
@@ -522,6 +535,8 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int gx, in
         case IGF2_CFG_64x256: return launch2_cfg<IGF2_CFG_64x256>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x256_W4: return launch2_cfg<IGF2_CFG_128x256_W4>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x512_W4: return launch2_cfg<IGF2_CFG_64x512_W4>(ntap, p, gx, gy, st);
+        case IGF2_CFG_128x320: return launch2_cfg<IGF2_CFG_128x320>(ntap, p, gx, gy, st);
+        case IGF2_CFG_64x640: return launch2_cfg<IGF2_CFG_64x640>(ntap, p, gx, gy, st);
     }
     return hipErrorInvalidValue;
 }

@@ -16,7 +16,7 @@ from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
 from tests import hiputil as hu  # noqa: E402
 
 
-@pytest.fixture(params=[0, 1, 2, 3])
+@pytest.fixture(params=[0, 1, 2, 3, 6, 7])
 def forced_cfg(request):
     old = os.environ.get("RSU_FWD2_CFG")
     os.environ["RSU_FWD2_CFG"] = str(request.param)
