@@ -69,3 +69,37 @@ def test_convT_fwd_every_shape(forced_cfg, N, H, W, Cin, Cout):
         y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
         call("rsu_convT2x2_fwd", hu.ptr(xd), hu.ptr(pf), hu.ptr(bd), hu.ptr(y), N, H, W, Cin, Cout, hu.stream())
         hu.assert_bf16_close(hu.host(y), ref, "convT fwd cfg %d rep %d" % (forced_cfg, rep))
+
+
+def test_dilated_three_source_and_accumulate_every_shape(forced_cfg):
+    """the remaining modes of the kernel on a multi-tile input: dilation 2, three cropped concat sources with odd channel counts,
+    and the accumulating backward-data (dilated branch adding onto the main branch's input gradient)"""
+    rng = np.random.RandomState(9)
+    N, h, w = 1, 76, 88
+    a = hu.q(_rand(rng, N, h + 12, w + 10, 48))
+    bsrc = hu.q(_rand(rng, N, h + 6, w + 4, 16))
+    c = hu.q(_rand(rng, N, h, w, 64))
+    Cout = 128 if forced_cfg in (0, 2, 6) else 64
+    W = _rand(rng, 3, 3, 128, Cout, scale=0.05)
+    bias = _rand(rng, Cout, scale=0.1)
+    ad, bd_, cd, biasd = hu.dev_bf16(a), hu.dev_bf16(bsrc), hu.dev_bf16(c), hu.dev_f32(bias)
+    wp = hu.pack_conv_fwd(W, [48, 16, 64])
+    srcs = (RsuSrc * 3)(hu.src_of(ad, h, w), hu.src_of(bd_, h, w), hu.src_of(cd, h, w))
+    cat = np.concatenate([U.center_crop(a, h, w), U.center_crop(bsrc, h, w), c], axis=3)
+    for dil in (1, 2):
+        ref = U.conv2d_fwd(cat, hu.q(W), bias, dil=dil)
+        for rep in range(2):
+            y = torch.full((N, h - 2 * dil, w - 2 * dil, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+            call("rsu_conv2d_fwd", srcs, 3, hu.ptr(wp), hu.ptr(biasd), hu.ptr(y), N, h, w, Cout, dil, 1, hu.stream())
+            hu.assert_bf16_close(hu.host(y), ref, "3-source conv dil %d cfg %d" % (dil, forced_cfg))
+    # accumulate: dx = base + Conv2DBackpropInput(dz) with dilation 2
+    Cin = 64
+    Wb = _rand(rng, 3, 3, Cin, Cout, scale=0.05)
+    dz = hu.q(_rand(rng, N, h - 4, w - 4, Cout, scale=0.1))
+    base = hu.q(_rand(rng, N, h, w, Cin, scale=0.1))
+    dzd, wb = hu.dev_bf16(dz), hu.pack_conv_bwd(Wb, 0, Cin)
+    ref = base + U.conv2d_bwd_data(dz, hu.q(Wb), (h, w), dil=2)
+    for rep in range(2):
+        dx = hu.dev_bf16(base).clone()
+        call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), None, 1, N, h, w, Cin, 0, Cin, Cout, 2, hu.stream())
+        hu.assert_bf16_close(hu.host(dx), ref, "accumulating bwd_data dil 2 cfg %d" % forced_cfg)
