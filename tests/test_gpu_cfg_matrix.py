@@ -103,3 +103,39 @@ def test_dilated_three_source_and_accumulate_every_shape(forced_cfg):
         dx = hu.dev_bf16(base).clone()
         call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), None, 1, N, h, w, Cin, 0, Cin, Cout, 2, hu.stream())
         hu.assert_bf16_close(hu.host(dx), ref, "accumulating bwd_data dil 2 cfg %d" % forced_cfg)
+
+
+@pytest.mark.parametrize("wg_cfg", [0, 2])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(1, 70, 75, 64, 192, 1), (2, 60, 60, 128, 128, 2)])
+def test_conv3x3_bwd_weight_both_shapes(wg_cfg, N, H, W, Cin, Cout, dil):
+    """weight-gradient kernel: 64x64 (two wave groups) and 128x64 workgroup shapes, multi-tile splits, three runs each"""
+    old = os.environ.get("RSU_WG_CFG")
+    os.environ["RSU_WG_CFG"] = str(wg_cfg)
+    try:
+        rng = np.random.RandomState(H + Cout + dil)
+        Ho, Wo = H - 2 * dil, W - 2 * dil
+        x = hu.q(_rand(rng, N, H, W, Cin))
+        dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
+        xd, dzd = hu.dev_bf16(x), hu.dev_bf16(dz)
+        ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=dil)
+        nws = lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout)
+        s = hu.src_of(xd, H, W)
+        first = None
+        for rep in range(3):
+            ws = torch.zeros(nws + 1024, dtype=torch.float32, device=hu.DEV)
+            ws[nws:] = 777.0
+            dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+            db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+            call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
+            hu.assert_f32_close(hu.host(dw), ref_dw, "bwd_weight cfg %d rep %d" % (wg_cfg, rep))
+            hu.assert_f32_close(hu.host(db), ref_db, "bias grad cfg %d rep %d" % (wg_cfg, rep))
+            assert bool((ws[nws:] == 777.0).all()), "workspace overrun"
+            if first is None:
+                first = hu.host(dw).copy()
+            else:
+                np.testing.assert_array_equal(hu.host(dw), first)  # fixed reduction order: bit-exact repeatability
+    finally:
+        if old is None:
+            os.environ.pop("RSU_WG_CFG", None)
+        else:
+            os.environ["RSU_WG_CFG"] = old
