@@ -196,8 +196,14 @@ igemm_wgrad_kernel(const IgWgradParams p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // staging loads of the tile nbuf-1 ahead: the first half of the waves issues them right behind the barrier, the second half
+        // (the SIMD partners) behind its first k-step -- each LDS-DMA instruction holds a wave's issue for ~100 cycles, and with
+        // both partners issuing at once the matrix pipe of the SIMD sat idle for that long every tile
         const int nxt = tile + (nbuf - 1) * p.nsplit;
-        if (nxt < p.ntiles_total && p.dbg != 1) issue(decode(p.dbg == 2 ? z : nxt), ibuf);
+        const bool have_nxt = nxt < p.ntiles_total && p.dbg != 1;
+        const int ibuf_now = ibuf;
+        const bool late = wave >= NW / 2;
+        if (have_nxt && !late) issue(decode(p.dbg == 2 ? z : nxt), ibuf_now);
         ibuf = ibuf + 1 == nbuf ? 0 : ibuf + 1;
         const int fb = buf * FBUF, sb = s_base + buf * SBUF;
         // A operand: F^T (rows = cf), two transposed reads per 16-channel tile
@@ -257,6 +263,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
                 for (int st = 0; st < CST; ++st) mfma_bf16_inplace(accs[st], ones, sv[step & 1][st]);
             }
+            if (step == NTAP - 1 && late && have_nxt) issue(decode(p.dbg == 2 ? z : nxt), ibuf_now);
             if (tap == 0 && do_bias) {
                 // the all-ones operand is re-materialised here (four v_mov per k-step) instead of living in four VGPRs
                 unsigned o1 = 0x3f803f80u;
