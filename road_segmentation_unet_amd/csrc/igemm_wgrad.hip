@@ -263,7 +263,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
 #pragma unroll
                 for (int st = 0; st < CST; ++st) mfma_bf16_inplace(accs[st], ones, sv[step & 1][st]);
             }
-            if (step == NTAP - 1 && late && have_nxt) issue(decode(p.dbg == 2 ? z : nxt), ibuf_now);
+            if (step == (KSG >= 4 ? 2 : 1) * NTAP - 1 && late && have_nxt) issue(decode(p.dbg == 2 ? z : nxt), ibuf_now);
             if (tap == 0 && do_bias) {
                 // the all-ones operand is re-materialised here (four v_mov per k-step) instead of living in four VGPRs
                 unsigned o1 = 0x3f803f80u;
