@@ -6,6 +6,7 @@ Data parallelism (new; the reference is single-device): when torch.distributed i
 minibatch, sharded contiguously over ranks; gradients are all-reduced (dist.GradBucketer); predict() shards tiles.
 """
 import glob
+import math
 import os
 from datetime import datetime
 
@@ -171,26 +172,102 @@ class ConvolutionalModel:
         assert (H - P) % opts.stride == 0, "Stride sliding should cover the whole image"
         pps = (H - P) // opts.stride + 1
         num_patches = num_images * pps * pps
-        per = -(-num_patches // self.world)
-        lo, hi = min(self.rank * per, num_patches), min((self.rank + 1) * per, num_patches)
         acc = dimages.OverlapAccumulator(num_images, H, P, opts.stride, device=dev)
         was_training = net.training
         net.training = False
-        for t0 in range(lo, hi, B):
-            nb = min(B, hi - t0)
-            if nb < B:
-                net.x.zero_()  # the reference pads the last batch with zero patches (tf_aerial_images.py:298-301)
-            dimages.extract_mirrored_patches(imgs_t, S, P, opts.stride, t0=t0, ntiles=nb, out=net.x[:nb])
-            net.forward_device()
-            acc.add(net.prob[:nb], t0)
+        reduced = False
+        if os.environ.get("RSU_PREDICT_SHARED", "1") == "1" and pps > 1:
+            tiles = self._shared_window_tiles(imgs_t, pps)
+            if self.world > 1:
+                dist.all_reduce(tiles)   # every rank filled the tiles of its own phase classes, zeros elsewhere
+            acc.add(tiles.view(-1, P, P), 0)
+            reduced = True   # (the tiles were exchanged before the overlap-add)
+        else:
+            per = -(-num_patches // self.world)
+            lo, hi = min(self.rank * per, num_patches), min((self.rank + 1) * per, num_patches)
+            for t0 in range(lo, hi, B):
+                nb = min(B, hi - t0)
+                if nb < B:
+                    net.x.zero_()  # the reference pads the last batch with zero patches (tf_aerial_images.py:298-301)
+                dimages.extract_mirrored_patches(imgs_t, S, P, opts.stride, t0=t0, ntiles=nb, out=net.x[:nb])
+                net.forward_device()
+                acc.add(net.prob[:nb], t0)
         net.training = was_training
-        if self.world > 1:
+        if self.world > 1 and not reduced:
             dist.all_reduce(acc.acc)
             dist.all_reduce(acc.hits)
         masks = acc.finish()
         if opts.ensemble_prediction:
             masks = dimages.invert_image_augmentation_ensemble(masks)
         return masks.cpu().numpy()
+
+    def _shared_window_tiles(self, imgs_t, pps):
+        """The sliding window of tf_aerial_images.py:288-320 without its redundancy. The network is fully convolutional with VALID
+        convolutions; its L-1 pools tie the result to the input offset modulo 2^(L-1) only. Tiles whose offsets agree modulo that
+        period (on both axes) are therefore sub-windows of ONE forward pass over the union of their input windows: with stride 12
+        and L = 6 the 19 x 19 tiles of a 604-pixel image fall into 8 x 8 phase classes of up to 3 x 3 tiles spaced lcm(12, 32) = 96
+        pixels apart -- 64 passes over <= 956-pixel windows instead of 361 passes over 764-pixel tiles (3.6x fewer FLOPs).
+        Every output element sees exactly the arithmetic of the per-tile pass (the reduction order of an output element does not
+        depend on the tile it lies in), so the tiles are bit-identical; they are assembled in the reference's tile order and
+        averaged by the same overlap kernel. Phase classes are dealt round-robin to the ranks.
+        Returns float32 [n, pps, pps, P, P] indexed [image][x index][y index] (this rank's classes; zeros elsewhere)."""
+        opts, net = self._options, self.net
+        dev = net.device
+        n, H = imgs_t.shape[0], imgs_t.shape[1]
+        P, S, L, stride = opts.patch_size, self.input_size, opts.num_layers, opts.stride
+        off = (S - P) // 2
+        period = 2 ** (L - 1)
+        g = stride * period // math.gcd(stride, period)   # spacing of same-phase tiles
+        # symmetric ("mirror_border", images.py:269-281) padding by index arithmetic; one extra window of zeros behind it
+        c = torch.arange(-off, H + off, device=dev)
+        idx = torch.where(c < 0, -c - 1, torch.where(c >= H, 2 * H - c - 1, c))
+        padded = imgs_t[:, idx][:, :, idx].contiguous()           # [n, Hp, Hp, 3]
+        Hp = padded.shape[1]
+        smax = int(os.environ.get("RSU_PREDICT_MAX_WINDOW", "1100"))   # largest input window (memory: ~1.7 GB per image at L = 6)
+        kmax = max(1, 1 + (smax - S) // g)
+        # per axis: tile indices of each phase class, cut into runs of <= kmax tiles spaced g apart
+        step = g // stride
+        runs = []
+        for first in range(min(step, pps)):
+            cls = list(range(first, pps, step))
+            runs += [cls[i:i + kmax] for i in range(0, len(cls), kmax)]
+        tiles = torch.zeros((n, pps, pps, P, P), dtype=torch.float32, device=dev)   # [img][xi][yi] = the reference's tile order
+        jobs = [(rx, ry) for rx in runs for ry in runs]
+        Bw = 2 if n % 2 == 0 else 1
+        for ji, (rx, ry) in enumerate(jobs):
+            if ji % self.world != self.rank:
+                continue
+            k = max(len(rx), len(ry))
+            Pk = P + (k - 1) * g
+            wn = self._window_net(Pk, Bw)
+            Sk = wn.S
+            ox0, oy0 = rx[0] * stride, ry[0] * stride
+            h, w = min(Sk, Hp - oy0), min(Sk, Hp - ox0)
+            for b0 in range(0, n, Bw):
+                if h < Sk or w < Sk:
+                    wn.x.zero_()
+                wn.x[:, :h, :w] = padded[b0:b0 + Bw, oy0:oy0 + h, ox0:ox0 + w]
+                wn.forward_device()
+                for a, xi in enumerate(rx):
+                    for bb, yi in enumerate(ry):
+                        tiles[b0:b0 + Bw, xi, yi] = wn.prob[:, bb * g:bb * g + P, a * g:a * g + P]
+        return tiles
+
+    def _window_net(self, Pk, Bw):
+        """a forward-only network for a larger output window, sharing this model's current weights"""
+        nets = self.__dict__.setdefault("_win_nets", {})
+        opts = self._options
+        wn = nets.get((Pk, Bw))
+        if wn is None:
+            wn = nets[Pk, Bw] = UNet(opts.num_layers, opts.root_size, opts.dilated_layers, Bw, Pk, device=self.net.device,
+                                     params=None, seed=opts.seed, training=False)
+            wn._weights_version = None
+        ver = (self.net.global_step, getattr(self.net, "_load_count", 0))
+        if wn._weights_version != ver:
+            wn.flat_w.copy_(self.net.flat_w)
+            wn.repack()
+            wn._weights_version = ver
+        return wn
 
     def predict_batchwise(self, imgs, pred_batch_size):
         """tf_aerial_images.py:330-341"""

@@ -147,6 +147,7 @@ class UNet:
         return d
 
     def load_state_dict(self, d):
+        self._load_count = getattr(self, "_load_count", 0) + 1
         for n in self.names:
             self.w[n].copy_(torch.from_numpy(np.ascontiguousarray(d[n], dtype=np.float32)))
             if n + "/Momentum" in d:

@@ -103,3 +103,51 @@ def test_pixel_f1_parity_after_training():
     f_hip, f_ref = pixel_f1(hip, yte), pixel_f1(ref, yte)
     assert f_ref > 0.6, f_ref   # the task was actually learned
     assert abs(f_hip - f_ref) <= 1e-3 + 2e-3, (f_hip, f_ref)
+
+
+@pytest.mark.parametrize("L,P,H,stride,dilated,ensemble", [(3, 20, 44, 12, True, True), (3, 20, 52, 2, False, False), (4, 28, 64, 6, True, False),
+                                                           (2, 12, 40, 4, False, True)])
+def test_shared_window_prediction_equals_tilewise(L, P, H, stride, dilated, ensemble):
+    """tiles with equal offsets modulo 2^(L-1) computed as sub-windows of one larger forward pass: the masks must be bit-identical to
+    the per-tile sliding window of tf_aerial_images.py:288-320 (every output element sees the same arithmetic)"""
+    import os
+    root = 16
+    rng = np.random.RandomState(L + stride)
+    imgs = rng.rand(2, H, H, 3).astype(np.float32)
+    params = U.init_params(L, root, dilated, seed=3, bias_scale=0.05)
+    opts = Options(num_layers=L, root_size=root, patch_size=P, stride=stride, dilated_layers=dilated, batch_size=4,
+                   ensemble_prediction=ensemble, dropout=1.0)
+    m = ConvolutionalModel(opts, params=params)
+    old = os.environ.get("RSU_PREDICT_SHARED")
+    try:
+        os.environ["RSU_PREDICT_SHARED"] = "0"
+        tilewise = m.predict(imgs)
+        os.environ["RSU_PREDICT_SHARED"] = "1"
+        shared = m.predict(imgs)
+        os.environ["RSU_PREDICT_MAX_WINDOW"] = str(m.input_size + 8)   # force runs of one or two tiles per axis
+        shared_small = m.predict(imgs)
+    finally:
+        os.environ.pop("RSU_PREDICT_MAX_WINDOW", None)
+        if old is None:
+            os.environ.pop("RSU_PREDICT_SHARED", None)
+        else:
+            os.environ["RSU_PREDICT_SHARED"] = old
+    # masks: the overlap average adds the same tiles in the same order but in different launch groupings (fp32 association)
+    np.testing.assert_allclose(shared, tilewise, rtol=0, atol=5e-7)
+    np.testing.assert_allclose(shared_small, tilewise, rtol=0, atol=5e-7)
+    # tiles: bit-identical to the per-tile forward pass
+    import torch
+    from road_segmentation_unet_amd import images as dimages
+    x = torch.as_tensor(imgs).to(m.net.device)
+    if ensemble:
+        x = dimages.image_augmentation_ensemble(x).contiguous()
+    pps = (H - P) // stride + 1
+    tiles = m._shared_window_tiles(x, pps)
+    m.net.training = False
+    B = m.local_batch
+    flat = tiles.view(-1, P, P)
+    for t0 in range(0, flat.shape[0], B):
+        nb = min(B, flat.shape[0] - t0)
+        dimages.extract_mirrored_patches(x, m.input_size, P, stride, t0=t0, ntiles=nb, out=m.net.x[:nb])
+        m.net.forward_device()
+        assert torch.equal(m.net.prob[:nb], flat[t0:t0 + nb]), t0

@@ -17,7 +17,7 @@ m = ConvolutionalModel(opts)
 imgs = np.random.RandomState(0).rand(a.images, a.size, a.size, 3).astype(np.float32)
 pps = (a.size - 388) // a.stride + 1
 ntiles = a.images * (1 if a.no_ensemble else 6) * pps * pps
-m.predict(imgs[:1, :412, :412])  # warm-up (small)
+m.predict(imgs[:1])  # warm-up at full size (builds the window networks of the shared-window path)
 torch.cuda.synchronize(); t0 = time.time()
 masks = m.predict(imgs)
 torch.cuda.synchronize(); dt = time.time() - t0
