@@ -233,7 +233,8 @@ class ConvolutionalModel:
             runs += [cls[i:i + kmax] for i in range(0, len(cls), kmax)]
         tiles = torch.zeros((n, pps, pps, P, P), dtype=torch.float32, device=dev)   # [img][xi][yi] = the reference's tile order
         jobs = [(rx, ry) for rx in runs for ry in runs]
-        Bw = 2 if n % 2 == 0 else 1
+        bmax = max(1, int(os.environ.get("RSU_PREDICT_WINDOW_BATCH", "6")))   # ~2 GB of activations per window image at L = 6
+        Bw = max(d for d in range(1, min(n, bmax) + 1) if n % d == 0)
         for ji, (rx, ry) in enumerate(jobs):
             if ji % self.world != self.rank:
                 continue
