@@ -280,6 +280,10 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 }
                 const u32x4 r = {r0, r1, r2, r3};
                 __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voffs[e], sbase, 0);
+                // the store's data registers are dead from here on and the compiler reuses them at once (a VALU write in the very
+                // next instruction); with an SGPR offset it sees no hazard in that, but the last lanes of the 128-bit store were
+                // observed to pick up the NEW value: keep four wait states behind every store
+                asm volatile("s_nop 3" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
         }
@@ -335,7 +339,12 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
                                                                                  ((wco * (CT / 2) + (ct >> 1)) * 32 + 8 * g4 + (ct & 1) * 4) * 4);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = bv;
+            for (int pt = 0; pt < PT; ++pt) {
+                acc[ct][pt] = bv;
+                // materialise the copy HERE: left to itself the compiler sinks it to just in front of the first (inline-asm) MFMA
+                // that reads it, closer than the matrix pipe tolerates (tools/check_mfma_hazards.py)
+                asm volatile("" : "+v"(acc[ct][pt]));
+            }
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
             // every wave may rely on the constant per-stage counts only while the two chunks ahead exist
@@ -413,8 +422,10 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 c_slot = c_slot == NWB - 1 ? 0 : c_slot + 1;
             }
             ca_slot = ca_slot == NAB - 1 ? 0 : ca_slot + 1;
+            // the results fence sits INSIDE the loop, straight behind the tile's last MFMA: register copies the compiler makes on
+            // the loop exit (they read the accumulators) then come after it
+            if (c == nchunks - 1) mfma_results_fence();
         }
-        mfma_results_fence();
         epilogue(ctile, acc);
     }
 }

@@ -29,14 +29,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, r);
 }
 
-// ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand).
-// Why not the builtin: under register pressure hipcc writes the result to a fresh tuple and re-uses the SrcC registers a few
-// instructions later (DMA addresses, selects). Its WAR distance is sized for one wave per SIMD; with two waves per SIMD (all
-// kernels here) an MFMA can sit behind the partner wave's MFMA before it starts reading SrcC, the later write lands first, and
-// a quarter of the lanes of one or two accumulator registers come out as address bits -- intermittently, only in the shapes
-// with 64 accumulator registers. With vDst == SrcC no register is freed by an MFMA, so nothing can be written over it early.
-// Consequences of the asm being opaque to the hazard recogniser: the caller keeps dependent MFMAs on one accumulator at least
-// 4 MFMAs apart (they are 16 apart here) and idles 32 cycles before the first VALU read of the results (mfma_results_fence).
+// ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand): no register is freed by
+// an MFMA, so the compiler cannot rename an accumulator and re-use its old registers while the matrix pipe still reads them.
+// The asm is opaque to hipcc's hazard recogniser, so the CALLER owns the wait states around it (DESIGN.md section 4;
+// tools/check_mfma_hazards.py checks them in the compiled ISA): dependent MFMAs on one accumulator at least 4 MFMAs apart
+// (they are 16 apart here), mfma_results_fence() straight behind the last MFMA before anything else reads the results, and an
+// operand written by a VALU instruction followed by `s_nop 3` before the MFMA that reads it.
 __device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
