@@ -53,7 +53,7 @@ template <int WCO, int WPX, int CT, int PT, int NTAP, int KW, int TPS, int NA, i
 __global__ void __launch_bounds__(WCO* WPX * 64) __attribute__((amdgpu_waves_per_eu(WCO* WPX / 4, WCO* WPX / 4)))
 igemm_fwd2_kernel(const IgFwdParams p) {
     constexpr int NW = WCO * WPX;
-    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(NW == 8, "eight waves: two per SIMD");
     constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
     constexpr int WT = TN / 16;
     constexpr int SPC = NTAP / TPS;
@@ -402,7 +402,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                             mfma_bf16_inplace(acc[ct][pt], fa[tl & 1][ct], fb[tl & 1][pt]);
                     // LDS-DMA bookkeeping for the stages ahead, placed BEHIND a block of MFMAs and staggered between the two
                     // waves of a SIMD (waves w and w+4): while one does scalar address work its partner feeds the matrix pipe
-                    if (TPS == 1 || NW == 4) {
+                    if (TPS == 1) {
                         if (tl == 0) prefetch();
                     } else {
                         if (tl == 0 && wave < NW / 2) prefetch();
@@ -459,14 +459,6 @@ template <> struct Fwd2Cfg<IGF2_CFG_64x640> {
     static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 5;
     static constexpr int na(int ntap) { return ntap == 1 ? 5 : 7; }
 };
-template <> struct Fwd2Cfg<IGF2_CFG_128x256_W4> {
-    static constexpr int WCO = 2, WPX = 2, CT = 4, PT = 8;
-    static constexpr int na(int) { return 7; }
-};
-template <> struct Fwd2Cfg<IGF2_CFG_64x512_W4> {
-    static constexpr int WCO = 1, WPX = 4, CT = 4, PT = 8;
-    static constexpr int na(int) { return 10; }
-};
 
 static constexpr int tps2_for(int TN, int ntap) { return ntap == 9 ? 3 : (ntap == 4 ? (TN <= 64 ? 4 : 2) : 1); }
 static constexpr int nab_for(int TN, int ntap) { return ntap / tps2_for(TN, ntap) == 1 ? 4 : 2; }
@@ -482,8 +474,6 @@ IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
         CASE(IGF2_CFG_64x256)
-        CASE(IGF2_CFG_128x256_W4)
-        CASE(IGF2_CFG_64x512_W4)
         CASE(IGF2_CFG_128x320)
         CASE(IGF2_CFG_64x640)
 #undef CASE
@@ -497,8 +487,6 @@ int igemm_fwd2_max_pieces(int cfg, int ntap) {
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
         CASE(IGF2_CFG_64x256)
-        CASE(IGF2_CFG_128x256_W4)
-        CASE(IGF2_CFG_64x512_W4)
         CASE(IGF2_CFG_128x320)
         CASE(IGF2_CFG_64x640)
 #undef CASE
@@ -544,8 +532,6 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int gx, in
         case IGF2_CFG_64x512: return launch2_cfg<IGF2_CFG_64x512>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x128: return launch2_cfg<IGF2_CFG_128x128>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x256: return launch2_cfg<IGF2_CFG_64x256>(ntap, p, gx, gy, st);
-        case IGF2_CFG_128x256_W4: return launch2_cfg<IGF2_CFG_128x256_W4>(ntap, p, gx, gy, st);
-        case IGF2_CFG_64x512_W4: return launch2_cfg<IGF2_CFG_64x512_W4>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x320: return launch2_cfg<IGF2_CFG_128x320>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x640: return launch2_cfg<IGF2_CFG_64x640>(ntap, p, gx, gy, st);
     }

@@ -314,7 +314,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
     bool have = false;
     for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
         if (force_cfg >= 0 && cfg != force_cfg) continue;
-        if (force_cfg < 0 && (cfg == IGF2_CFG_128x256_W4 || cfg == IGF2_CFG_64x512_W4)) continue;  // the 4-wave shapes are kept for A/B runs only
+        if (igemm_fwd2_cfg_info(cfg).TN == 0) continue;  // retired ids
         if (force_cfg < 0 && (cfg == IGF2_CFG_128x320 || cfg == IGF2_CFG_64x640) && !env_int("RSU_CFG_320", 1)) continue;
         const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
         if (Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;

@@ -90,6 +90,7 @@ def main():
         call("rsu_pack_conv_fwd", ptr(w), ptr(pf), 3, cin, cout, seg, 1, st)
         call("rsu_pack_conv_bwd", ptr(w), ptr(pb), 3, cin, 0, cin, cout, st)
         dw = torch.zeros_like(w)
+        db = torch.zeros(cout, device=DEV)
         ws = torch.zeros(lib().rsu_conv2d_bwd_weight_ws_floats(cin, cin, cout), device=DEV)
         src = RsuSrc(x.data_ptr(), hin, hin, cin, 0, 0)
         arr = (RsuSrc * 1)(src)
@@ -109,7 +110,7 @@ def main():
                     elif op == "bwdnm":  # backward-data without the ReLU mask (A/B: cost of the mask loads in the epilogue)
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, st))
                     else:
-                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
+                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
                     line += " %s%s %6.0fus %5.0fTF |" % (op, "" if cfg < 0 else "[%d]" % cfg, t * 1e6, fl / t / 1e12)
                     tot[(op, cfg)] = tot.get((op, cfg), 0.0) + t
                 except Exception as ex:
