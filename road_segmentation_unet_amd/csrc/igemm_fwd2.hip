@@ -120,6 +120,10 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     // buffer descriptors are rebuilt from the (scalar) kernel-argument pointers right where they are used: hoisting them
     // makes hipcc park them in VGPRs/scratch and wrap every buffer op in a waterfall loop (cdna guide T20)
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
+    auto desc_words = [&](const void* ptr) {  // raw buffer descriptor: base, stride 0, num_records 0x7fffffff, dword 3 as in mk()
+        const unsigned long a = (unsigned long)ptr;
+        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+    };
 
     // ---- weight prefetch stream. Stage s of a tile reads the contiguous block [s*TPS .. s*TPS+TPS) x [all tiles] of the
     // packed weights, so the source is one scalar pointer that advances by a constant per stage and rewinds per tile;
@@ -222,12 +226,25 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ordinary loads before the LDS-DMA stream starts
     __syncthreads();
 
+    // scalar byte offset of a tile's first output pixel (+ this wave's first channel) and per-lane offset of epilogue store e
+    auto out_sbase = [&](const Tile& T) {
+        return (unsigned)((((long)(T.n * p.oH + T.y0 * p.ostride + ooffy) * p.oW + T.x0 * p.ostride + ooffx) * p.outC + cob * TN +
+                           wco * (CT / 2) * 32) * 2);
+    };
+    auto out_voff = [&](const Tile& T, int e) {
+        const int pt = e / (CT / 2), pp = e % (CT / 2);
+        const int ml = (wpx * PT + pt) * 16 + l15;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
+        const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
+        const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
+        return (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
+    };
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
+        const u32x4 odesc = desc_words(p.out);  // the same descriptor as plain words, for the inline-asm store
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
-        // scalar byte offset of the tile's first output pixel (+ this wave's first channel)
-        const unsigned sbase = (unsigned)((((long)(T.n * p.oH + T.y0 * p.ostride + ooffy) * p.oW + T.x0 * p.ostride + ooffx) * p.outC +
-                                           cob * TN + wco * (CT / 2) * 32) * 2);
+        const unsigned sbase = out_sbase(T);
         // NST stores in batches of four: the mask / accumulate loads of a batch are requested together (one memory latency per
         // batch instead of one per store); larger batches would need more than the 16-32 VGPRs that are free here
         constexpr int EB = NST % 4 == 0 ? 4 : 2;
@@ -238,13 +255,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             u32x4 mk4[EB], ob4[EB];
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                const int pt = (b0 + e) / (CT / 2), pp = (b0 + e) % (CT / 2);
-                const int ml = (wpx * PT + pt) * 16 + l15;
-                const int ty = ml >> lsw, tx = ml & (SW - 1);
-                const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
-                const int ovoff_pt = ((ty * p.ostride * p.oW + tx * p.ostride) * p.outC + 8 * g4) * 2;
-                const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
-                voffs[e] = (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
+                voffs[e] = out_voff(T, b0 + e);
                 if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
                 if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
             }
@@ -279,11 +290,14 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                     r3 = relu_pk_bf16(r3);
                 }
                 const u32x4 r = {r0, r1, r2, r3};
-                __builtin_amdgcn_raw_buffer_store_b128(r, orsrc, voffs[e], sbase, 0);
                 // the store's data registers are dead from here on and the compiler reuses them at once (a VALU write in the very
                 // next instruction); with an SGPR offset it sees no hazard in that, but the last lanes of the 128-bit store were
-                // observed to pick up the NEW value: keep four wait states behind every store
-                asm volatile("s_nop 3" ::: "memory");
+                // observed to pick up the NEW value. Store and four wait states are ONE asm statement, so
+                // nothing can be scheduled in between
+                // (and five in front: the compiler may restore a spilled descriptor word with v_readlane right before the
+                // statement, and a VMEM read of a VALU-written SGPR needs five wait states it cannot know about here)
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(odesc), "s"(sbase)
+                             : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
         }
@@ -426,7 +440,7 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             // the loop exit (they read the accumulators) then come after it
             if (c == nchunks - 1) mfma_results_fence();
         }
-        epilogue(ctile, acc);
+        if (!(p.dbg & 8)) epilogue(ctile, acc);  // dbg bit 3: timing experiment without the epilogue (results are not written)
     }
 }
 

@@ -55,3 +55,12 @@ def test_library_isa_is_clean():
         assert want in names, "no saved ISA for %s" % want
     bad = sum(chk.check(f) for f in files)
     assert bad == 0, "%d register hazards in the compiled kernels (see the captured output)" % bad
+
+
+def test_rule_asm_vmem_reads_valu_written_sgpr(tmp_path, capsys):
+    st = "\t;;#ASMSTART\n\tbuffer_store_dwordx4 v[32:35], v139, s[88:91], s21 offen\n\t;;#ASMEND\n"
+    assert _count(tmp_path, "\tv_readlane_b32 s91, v228, 39\n" + st) == 1
+    assert _count(tmp_path, "\tv_readlane_b32 s91, v228, 39\n\t;;#ASMSTART\n\ts_nop 4\n\tbuffer_store_dwordx4 v[32:35], v139, s[88:91], s21 offen\n\t;;#ASMEND\n") == 0
+    assert _count(tmp_path, "\tv_readlane_b32 s80, v228, 39\n" + st) == 0
+    # the compiler covers its own (non-asm) VMEM instructions
+    assert _count(tmp_path, "\tv_readlane_b32 s91, v228, 39\n\tbuffer_store_dwordx2 v[32:33], v139, s[88:91], s21 offen\n") == 0

@@ -11,6 +11,8 @@ and reports
       hipcc only separates the two when the store has no SGPR offset (the documented hazard); on gfx950 the store's last
       lanes were observed to pick up the new register value with an SGPR offset as well (the epilogue stores of
       igemm_fwd2, once per ~1e4 launches), so every wide store is checked here whatever its addressing.
+  (4) any inline-asm VMEM instruction that reads an SGPR a VALU instruction (v_readlane, v_readfirstlane, v_cmp ...) wrote fewer
+      than SGPR_WS wait states earlier -- e.g. a spilled descriptor word restored right in front of an asm store.
 A wait state is one issued instruction of the same wave (s_nop N counts N+1); instructions of other waves do not count, so the
 check is conservative. usage: check_mfma_hazards.py file.s [...]; exit status 1 when anything is reported."""
 import re
@@ -19,8 +21,10 @@ import sys
 RESULT_WS = 16   # required by the ISA for the 16x16x32 bf16 MFMA: <= 12
 OPERAND_WS = 3   # VALU write -> MFMA read: 2
 STORE_WS = 2     # wide VMEM store -> VALU overwrite of its data registers (see (3) below); documented: 1
+SGPR_WS = 5      # VALU write of an SGPR -> (inline-asm) VMEM instruction that reads it; documented: 5
 
 REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+SREG = re.compile(r"\bs(?:(\d+)|\[(\d+):(\d+)\])")
 LABEL = re.compile(r"^([.\w$]+):")
 
 
@@ -30,6 +34,15 @@ def regs_of(operand):
         lo = int(m.group(2) if m.group(2) is not None else m.group(3))
         hi = int(m.group(2) if m.group(2) is not None else m.group(4))
         out.update((m.group(1), r) for r in range(lo, hi + 1))
+    return out
+
+
+def sregs_of(operand):
+    out = set()
+    for m in SREG.finditer(operand):
+        lo = int(m.group(1) if m.group(1) is not None else m.group(2))
+        hi = int(m.group(1) if m.group(1) is not None else m.group(3))
+        out.update(range(lo, hi + 1))
     return out
 
 
@@ -58,6 +71,17 @@ class Ins:
                                "scratch_store_dwordx3", "scratch_store_dwordx4")):
             return regs_of(self.ops[1])
         return set()
+
+    def is_vmem(self):
+        return self.op.startswith(("buffer_", "global_", "flat_", "scratch_"))
+
+    def valu_sgpr_writes(self):
+        if not self.op.startswith("v_") or not self.ops:
+            return set()
+        w = sregs_of(self.ops[0])
+        if self.op.endswith("_e64") and len(self.ops) > 1 and self.op.startswith(("v_add_co", "v_sub_co", "v_addc", "v_subb", "v_div_scale", "v_mad_u64", "v_mad_i64")):
+            w |= sregs_of(self.ops[1])
+        return w
 
     def valu_writes(self):
         if not self.op.startswith("v_") or self.is_mfma() or not self.ops:
@@ -164,6 +188,18 @@ def check(path):
                         return True
                     walk(ins, labels, i, STORE_WS, visit3)
                     n_store += 1
+                sw = I.valu_sgpr_writes()
+                if sw:
+                    def visit4(j, el, sw=sw, I=I):
+                        nonlocal bad
+                        J = ins[j]
+                        if J.asm and J.is_vmem() and any(sregs_of(o) & sw for o in J.ops):
+                            print("%s:%d %s: asm '%s' reads an SGPR written by VALU line %d only %d wait states earlier" % (
+                                path, J.line, name[:60], J.text, I.line, el))
+                            bad += 1
+                            return False
+                        return True
+                    walk(ins, labels, i, SGPR_WS, visit4)
                 w = I.valu_writes()
                 if not w:
                     continue
