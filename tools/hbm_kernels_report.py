@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Achieved HBM GB/s of the bandwidth-bound kernels of the config-2 step: algorithmic bytes per step (each tensor counted once,
+SURVEY section 8d) / the kernel's time per step from a rocprofv3 kernel-stats csv (tools/gpu_bench_profile.sh).
+usage: python tools/hbm_kernels_report.py profiles/r01/g_kernel_stats.csv [steps_in_profile=15] > profiles/r01/hbm_kernels.md"""
+import csv
+import sys
+
+L, ROOT, P, B = 5, 64, 388, 4
+S = P + 12 * 2 ** (L - 1) - 8
+path = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+
+# encoder geometry: conv2 output of level i (the pool input) and the decoder stage sizes
+pool_in, h, nf = [], S, ROOT
+for i in range(L - 1):
+    pool_in.append(B * (h - 4) ** 2 * nf)
+    h, nf = (h - 4) // 2, nf * 2
+n_pool_in = sum(pool_in)
+n_param = 31031822
+npix_out, npix_in = B * P * P, B * S * S
+alg = {  # kernel-name prefix -> (what, bytes per step)
+    "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout): 2 B read + 0.5 B written per input element", 2.5 * n_pool_in),
+    "_Z20k_pool_skip_relu_bwd": ("pool bwd + skip-gradient add + ReLU mask: 5.25 B per input element", 5.25 * n_pool_in),
+    "_Z10k_momentum": ("Momentum step: w, a, g read, w, a written (20 B per parameter)", 20.0 * n_param),
+    "_Z11k_pack_many": ("f32 -> bf16 MFMA fragment order, forward + backward pack (4 B read once per pack + 2 B written)", 12.0 * n_param),
+    "_Z6k_head": ("1x1 head + softmax + CE + gradients: 128 B read + 128 B written per output pixel", 256.0 * npix_out),
+    "_Z14k_color_adjust": ("centre + colour adjust: 12 B read + 32 B written per input pixel", 44.0 * npix_in),
+}
+rows = list(csv.DictReader(open(path)))
+print("| kernel | algorithmic traffic | MB / step | us / step | achieved GB/s | of 8 TB/s |")
+print("|---|---|---|---|---|---|")
+for pre, (what, nbytes) in alg.items():
+    t = sum(int(r["TotalDurationNs"]) for r in rows if r["Name"].startswith(pre)) / steps
+    if t == 0:
+        continue
+    gbs = nbytes / t
+    print("| `%s` | %s | %.0f | %.1f | %.0f | %.0f %% |" % (pre[pre.index("k_"):], what, nbytes / 1e6, t / 1e3, gbs, gbs / 80.0))
