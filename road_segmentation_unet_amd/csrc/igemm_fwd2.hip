@@ -120,10 +120,6 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     // buffer descriptors are rebuilt from the (scalar) kernel-argument pointers right where they are used: hoisting them
     // makes hipcc park them in VGPRs/scratch and wrap every buffer op in a waterfall loop (cdna guide T20)
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
-    auto desc_words = [&](const void* ptr) {  // raw buffer descriptor: base, stride 0, num_records 0x7fffffff, dword 3 as in mk()
-        const unsigned long a = (unsigned long)ptr;
-        return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
-    };
 
     // ---- weight prefetch stream. Stage s of a tile reads the contiguous block [s*TPS .. s*TPS+TPS) x [all tiles] of the
     // packed weights, so the source is one scalar pointer that advances by a constant per stage and rewinds per tile;
@@ -242,7 +238,6 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     };
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
-        const u32x4 odesc = desc_words(p.out);  // the same descriptor as plain words, for the inline-asm store
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
         // NST stores in batches of four: the mask / accumulate loads of a batch are requested together (one memory latency per
@@ -293,10 +288,9 @@ igemm_fwd2_kernel(const IgFwdParams p) {
                 // the store's data registers are dead from here on and the compiler reuses them at once (a VALU write in the very
                 // next instruction); with an SGPR offset it sees no hazard in that, but the last lanes of the 128-bit store were
                 // observed to pick up the NEW value. Store and four wait states are ONE asm statement, so
-                // nothing can be scheduled in between
-                // (and five in front: the compiler may restore a spilled descriptor word with v_readlane right before the
-                // statement, and a VMEM read of a VALU-written SGPR needs five wait states it cannot know about here)
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(odesc), "s"(sbase)
+                // nothing can be scheduled in between. (The descriptor and offset SGPRs must not come from a VALU instruction --
+                // v_readlane of a spilled word -- within five wait states: rule (4) of tools/check_mfma_hazards.py watches that.)
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(orsrc), "s"(sbase)
                              : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
