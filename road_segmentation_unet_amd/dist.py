@@ -81,3 +81,32 @@ class GradBucketer:
         if self.cuda:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
         self.pending = []
+
+
+def tune_overlap(bucketer, step, trials=3):
+    """Pick the gradient-exchange schedule by measurement: `step()` (one full training step that calls bucketer.reset/ready/finish)
+    runs `trials` times with the tail-first overlapped buckets and `trials` times with one all-reduce after backward; the
+    schedule with the smaller max-over-ranks time stays selected (every rank sees the same reduced timings, so all agree).
+    Which one wins depends on how RCCL's channel workgroups and the persistent conv workgroups share the CUs of the node at
+    hand, which no single-GPU run can tell. Returns {"overlap": chosen, "ms": {True: t, False: t}}."""
+    import time
+    if bucketer is None or bucketer.world == 1:
+        return {"overlap": bool(bucketer.overlap) if bucketer is not None else False, "ms": {}}
+    dev = bucketer.flat.device
+    timings = {}
+    for mode in (True, False):
+        bucketer.overlap = mode
+        step()  # settle (stream creation, RCCL channel setup for this message pattern)
+        if bucketer.cuda:
+            torch.cuda.synchronize(dev)
+        dist.barrier(group=bucketer.group)
+        t0 = time.perf_counter()
+        for _ in range(trials):
+            step()
+        if bucketer.cuda:
+            torch.cuda.synchronize(dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=bucketer.group)
+        timings[mode] = float(t.item()) / trials * 1e3
+    bucketer.overlap = timings[True] <= timings[False]
+    return {"overlap": bucketer.overlap, "ms": timings}

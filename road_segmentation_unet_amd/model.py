@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import images as dimages
-from .dist import GradBucketer, shard_indices
+from .dist import GradBucketer, shard_indices, tune_overlap
 from .unet import UNet, input_size_needed
 
 # (name, type, default, help) -- tf_aerial_images.py:15-46, same order
@@ -98,6 +98,8 @@ class ConvolutionalModel:
                         params=params, seed=opts.seed, training=True)
         self.net.dropout_seed = int(opts.seed) + 7919 * self.rank  # independent masks on every rank's shard
         self._bucketer = None
+        self._exchange_tuned = False
+        self.exchange_schedule = None
         if self.world > 1:
             self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
             self._bucketer.extra_streams = [self.net.wstream]
@@ -113,6 +115,17 @@ class ConvolutionalModel:
         opts, net = self._options, self.net
         net.x.copy_(torch.as_tensor(patches).to(net.device, torch.float32))
         net.labels.copy_(torch.as_tensor(labels).to(net.device, torch.int64))
+        if self._bucketer is not None and not self._exchange_tuned:
+            # first step of a data-parallel run: time forward + backward + exchange (no optimizer step, so the trajectory is
+            # untouched) under both schedules and keep the faster one (dist.tune_overlap)
+            self._exchange_tuned = True
+            if "RSU_DP_OVERLAP" not in os.environ:
+                def probe():
+                    net.forward_device(keep=float(opts.dropout))
+                    self._bucketer.reset()
+                    net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
+                    self._bucketer.finish()
+                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2)
         # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
         # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
         net.forward_device(keep=float(opts.dropout))

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from road_segmentation_unet_amd.dist import GradBucketer, shard_indices
+from road_segmentation_unet_amd.dist import GradBucketer, shard_indices, tune_overlap
 
 
 def _free_port():
@@ -57,7 +57,20 @@ def _worker(rank, world, port, q):
         _, _, gfull = U.loss_and_grads(params, X, labels, L, root, False)
         ref = torch.cat([torch.from_numpy(gfull[k].ravel()) for k in sorted(gfull)])
         err = float((flatg - ref).abs().max() / ref.abs().max())
-        q.put((rank, ok1, ok2, ok3, err, list(map(int, mine))))
+        # ---- schedule selection by measurement: every rank must end up with the same choice, and a step still reduces correctly
+        tflat = torch.zeros(4096)
+        tb = GradBucketer(tflat, 4096, min_bucket_elems=512)
+
+        def step():
+            tflat.fill_(float(rank + 1))
+            tb.reset()
+            for lo in (3000, 2000, 1000):
+                tb.ready(lo)
+            tb.finish()
+        tuned = tune_overlap(tb, step, trials=2)
+        step()
+        ok4 = bool((tflat == sum(range(1, world + 1))).all()) and set(tuned["ms"]) == {True, False} and tuned["overlap"] == tb.overlap
+        q.put((rank, ok1, ok2, ok3 and ok4, err, list(map(int, mine)), bool(tuned["overlap"])))
     finally:
         dist.destroy_process_group()
 
@@ -74,10 +87,13 @@ def test_two_rank_gloo_bucketed_allreduce_and_dp_equivalence():
         p.join(timeout=60)
         assert p.exitcode == 0
     shards = {}
-    for rank, ok1, ok2, ok3, err, mine in res:
+    choices = set()
+    for rank, ok1, ok2, ok3, err, mine, chosen in res:
         assert ok1 and ok2 and ok3, (rank, ok1, ok2, ok3)
         assert err < 1e-5, err
         shards[rank] = mine
+        choices.add(chosen)
+    assert len(choices) == 1, "ranks disagree on the exchange schedule"
     assert shards[0] == [0, 1] and shards[1] == [2, 3]
 
 
