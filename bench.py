@@ -34,6 +34,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from road_segmentation_unet_amd._lib import call, lib  # noqa: E402
 from road_segmentation_unet_amd.dist import GradBucketer, tune_overlap  # noqa: E402
 from road_segmentation_unet_amd.unet import UNet, input_size_needed  # noqa: E402
 
@@ -143,7 +144,7 @@ def main():
     dp_tune = None
     if bucketer is not None and "RSU_DP_OVERLAP" not in os.environ:
         # untimed: measure both gradient-exchange schedules on this node and keep the faster one (dist.tune_overlap)
-        dp_tune = tune_overlap(bucketer, lambda: run_step(m, bucketer, lr, mu))
+        dp_tune = tune_overlap(bucketer, lambda: run_step(m, bucketer, lr, mu), set_cu_budget=lambda n: call("rsu_set_cu_budget", n))
     for _ in range(args.warmup):
         run_step(m, bucketer, lr, mu)
     torch.cuda.synchronize()
@@ -215,9 +216,9 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "step_tflops_algorithmic": tot_fl * world * args.steps / dt / 1e12, "loss": loss,
                    "dp_exchange": (None if bucketer is None else
-                                   {"overlapped_buckets": bool(bucketer.overlap),
-                                    "tuned_ms_per_step": None if dp_tune is None else {("overlapped" if k else "single"): v
-                                                                                        for k, v in dp_tune["ms"].items()}})},
+                                   {"overlapped_buckets": bool(bucketer.overlap), "conv_cu_budget": lib().rsu_get_cu_budget(),
+                                    "tuned_ms_per_step": None if dp_tune is None else {
+                                        "%s/%dcu" % ("overlapped" if k[0] else "single", k[1]): v for k, v in dp_tune["ms"].items()}})},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "kernel": "3x3 conv MFMA kernels: igemm_fwd (fwd, bwd-data) + igemm_wgrad",

@@ -50,6 +50,10 @@ typedef struct {
 /* ---- library / device ------------------------------------------------------------------- */
 const char* rsu_version(void);
 int rsu_last_hip_error(void);
+/* Compute units the persistent conv launches plan for (32..256, default 256 = the whole MI355X). New here (the reference is
+ * single-device): a data-parallel host may leave some CUs to the RCCL channel workgroups of an overlapped gradient all-reduce. */
+int rsu_set_cu_budget(int ncu);
+int rsu_get_cu_budget(void);
 /* unet.py:100-115 input_size_needed(output_size, num_layers). RSU_EINVAL where the reference asserts. */
 int rsu_input_size_needed(int output_size, int num_layers, int* input_size);
 

@@ -23,6 +23,8 @@ _PI = ctypes.POINTER(ctypes.c_int)
 SIGNATURES = {
     "rsu_version": (ctypes.c_char_p, []),
     "rsu_last_hip_error": (_i, []),
+    "rsu_set_cu_budget": (_i, [_i]),
+    "rsu_get_cu_budget": (_i, []),
     "rsu_input_size_needed": (_i, [_i, _i, _PI]),
     "rsu_packed_bytes": (_sz, [_i, _i, _PI, _i]),
     "rsu_pack_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _PI, _i, _vp]),

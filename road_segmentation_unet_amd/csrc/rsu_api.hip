@@ -34,6 +34,15 @@ static inline int env_int(const char* name, int dflt) {
 
 extern "C" const char* rsu_version(void) { return "rsu-hip 0.1 (gfx950)"; }
 extern "C" int rsu_last_hip_error(void) { return g_last_hip_error.load(); }
+// CUs the persistent conv launches plan for (one workgroup each). 256 = the whole chip; a data-parallel run may leave a few to
+// RCCL's channel workgroups, which cannot share a CU with a persistent workgroup (dist.py picks the value by measurement)
+static std::atomic<int> g_cu_budget{256};
+extern "C" int rsu_set_cu_budget(int ncu) {
+    if (ncu < 32 || ncu > 256) return RSU_EINVAL;
+    g_cu_budget.store(ncu);
+    return RSU_OK;
+}
+extern "C" int rsu_get_cu_budget(void) { return g_cu_budget.load(); }
 
 extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input_size) {
     // unet.py:100-115: (L-1) x { assert even; o = (o+4)/2 }, (L-1) x { o = (o+4)*2 }, +4
@@ -329,7 +338,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
         const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
-        long workers = 256 / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
+        long workers = g_cu_budget.load() / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
         if (workers < 1) workers = 1;
         if (workers > ntile_m) workers = ntile_m;
         const long rounds = (ntile_m + workers - 1) / workers;
@@ -500,8 +509,8 @@ static int wgrad_pick_cfg(int cfg, int Cf) {
     return cfg;
 }
 // grid.z splits of the pixel reduction: one workgroup per CU in total
-static int wgrad_max_split(int cfg, int Cf, int Cs) {
-    int want = 256 / (cdiv(Cf, igemm_wgrad_cfb(cfg)) * cdiv(Cs, igemm_wgrad_csb(cfg)));
+static int wgrad_max_split(int cfg, int Cf, int Cs, int ncu = 256) {
+    int want = ncu / (cdiv(Cf, igemm_wgrad_cfb(cfg)) * cdiv(Cs, igemm_wgrad_csb(cfg)));
     return want < 1 ? 1 : want;
 }
 // slabs the workspace must hold (either shape the launch may pick)
@@ -532,7 +541,7 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
     pl.gx = cdiv(Cf, cfbk);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
-    const int want = wgrad_max_split(cfg, Cf, Cs);  // workgroups along z; each writes one slab
+    const int want = wgrad_max_split(cfg, Cf, Cs, g_cu_budget.load());  // workgroups along z; each writes one slab (workspace sized for 256)
     pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
     (void)ntap;
     return true;

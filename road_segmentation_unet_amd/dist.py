@@ -83,19 +83,29 @@ class GradBucketer:
         self.pending = []
 
 
-def tune_overlap(bucketer, step, trials=3):
-    """Pick the gradient-exchange schedule by measurement: `step()` (one full training step that calls bucketer.reset/ready/finish)
-    runs `trials` times with the tail-first overlapped buckets and `trials` times with one all-reduce after backward; the
-    schedule with the smaller max-over-ranks time stays selected (every rank sees the same reduced timings, so all agree).
-    Which one wins depends on how RCCL's channel workgroups and the persistent conv workgroups share the CUs of the node at
-    hand, which no single-GPU run can tell. Returns {"overlap": chosen, "ms": {True: t, False: t}}."""
+EXCHANGE_CANDIDATES = ((True, 256), (True, 240), (True, 224), (False, 256))  # (overlapped buckets?, CU budget of the conv launches)
+
+
+def tune_overlap(bucketer, step, trials=3, candidates=EXCHANGE_CANDIDATES, set_cu_budget=None):
+    """Pick the gradient-exchange schedule by measurement: `step()` (forward + backward with bucketer.reset/ready/finish) runs
+    `trials` times under every candidate -- tail-first overlapped buckets with the conv launches planned for 256, 240 or 224
+    CUs (RCCL's channel workgroups and a persistent conv workgroup cannot share a CU: with all 256 taken, a conv launch that
+    starts while an all-reduce is resident waits for CUs and roughly doubles), or one all-reduce after backward -- and the
+    candidate with the smallest max-over-ranks time stays selected (every rank sees the same reduced timings, so all agree).
+    Which one wins depends on the node at hand, which no single-GPU run can tell.
+    set_cu_budget: callable(int) (the library's rsu_set_cu_budget); None = budgets other than 256 are skipped.
+    Returns {"overlap": bool, "cu_budget": int, "ms": {(overlap, budget): ms_per_step}}."""
     import time
     if bucketer is None or bucketer.world == 1:
-        return {"overlap": bool(bucketer.overlap) if bucketer is not None else False, "ms": {}}
+        return {"overlap": bool(bucketer.overlap) if bucketer is not None else False, "cu_budget": 256, "ms": {}}
     dev = bucketer.flat.device
     timings = {}
-    for mode in (True, False):
+    for mode, budget in candidates:
+        if budget != 256 and set_cu_budget is None:
+            continue
         bucketer.overlap = mode
+        if set_cu_budget is not None:
+            set_cu_budget(budget)
         step()  # settle (stream creation, RCCL channel setup for this message pattern)
         if bucketer.cuda:
             torch.cuda.synchronize(dev)
@@ -107,6 +117,9 @@ def tune_overlap(bucketer, step, trials=3):
             torch.cuda.synchronize(dev)
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=bucketer.group)
-        timings[mode] = float(t.item()) / trials * 1e3
-    bucketer.overlap = timings[True] <= timings[False]
-    return {"overlap": bucketer.overlap, "ms": timings}
+        timings[(mode, budget)] = float(t.item()) / trials * 1e3
+    best = min(timings, key=lambda k: (timings[k], not k[0], -k[1]))
+    bucketer.overlap = best[0]
+    if set_cu_budget is not None:
+        set_cu_budget(best[1])
+    return {"overlap": best[0], "cu_budget": best[1], "ms": timings}

@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import images as dimages
+from ._lib import call
 from .dist import GradBucketer, shard_indices, tune_overlap
 from .unet import UNet, input_size_needed
 
@@ -125,7 +126,7 @@ class ConvolutionalModel:
                     self._bucketer.reset()
                     net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
                     self._bucketer.finish()
-                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2)
+                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=lambda n: call("rsu_set_cu_budget", n))
         # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
         # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
         net.forward_device(keep=float(opts.dropout))
