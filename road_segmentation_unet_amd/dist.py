@@ -83,12 +83,12 @@ class GradBucketer:
         self.pending = []
 
 
-EXCHANGE_CANDIDATES = ((True, 256), (True, 240), (True, 224), (False, 256))  # (overlapped buckets?, CU budget of the conv launches)
+EXCHANGE_CANDIDATES = ((True, 256), (True, 240), (True, 224), (True, 208), (False, 256))  # (overlapped buckets?, CU budget of the conv launches)
 
 
 def tune_overlap(bucketer, step, trials=3, candidates=EXCHANGE_CANDIDATES, set_cu_budget=None):
     """Pick the gradient-exchange schedule by measurement: `step()` (forward + backward with bucketer.reset/ready/finish) runs
-    `trials` times under every candidate -- tail-first overlapped buckets with the conv launches planned for 256, 240 or 224
+    `trials` times under every candidate -- tail-first overlapped buckets with the conv launches planned for 256, 240, 224 or 208
     CUs (RCCL's channel workgroups and a persistent conv workgroup cannot share a CU: with all 256 taken, a conv launch that
     starts while an all-reduce is resident waits for CUs and roughly doubles), or one all-reduce after backward -- and the
     candidate with the smallest max-over-ranks time stays selected (every rank sees the same reduced timings, so all agree).
