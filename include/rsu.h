@@ -115,6 +115,10 @@ size_t rsu_conv_first_bwd_ws_floats(int Cout);
 /* db (optional): BiasAddGrad of this conv, computed by the same launch */
 int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gx, float* db, float* ws, int N,
                               int H, int W, int Cout, int dil, rsu_stream_t stream);
+/* The two sums above in one launch: dW0 f32 [3][3] ([ci][cj]) and db0 f32 [3] from gx [9][12][Cout] and W1 f32 HWIO
+ * [3][3][3][Cout]; scale = 1/keep. accumulate != 0 adds to dW0/db0 (the dilated twin conv_dilut_0 shares color_space_adjust). */
+int rsu_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate,
+                         rsu_stream_t stream);
 /* unet.py:95 weight_output 1x1 conv (C -> 2) fused with tf_aerial_images.py:147-148 softmax[...,1].
  * act bf16 [npix][C]; w f32 [C][2]; prob f32 [npix]; logits f32 [npix][2] or NULL (unet.forward's return value). */
 int rsu_head_fwd(const void* act, const float* w, const float* b, float* prob, float* logits, long npix, int C,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv_first_bwd_ws_floats": (_sz, [_i]),
     "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_color_adjust_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "rsu_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     "rsu_head_ws_floats": (_sz, [_l, _i]),
     "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),

@@ -25,6 +25,7 @@ hipError_t ew_reduce_slabs(const float* slab, float* out, float* out2, int n2, i
 int ew_head_blocks(long npix, int C);
 hipError_t ew_head(bool train, const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* logits, void* dact, float* dw,
                    float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st);
+hipError_t ew_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate, hipStream_t st);
 hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, hipStream_t st);
 hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_t st);
 struct PackJob { PackParams pp; const float* src; bf16_t* dst; int block_start; int pad_; };

@@ -413,6 +413,27 @@ __global__ void __launch_bounds__(256) k_head_final(const float* __restrict__ pa
     }
 }
 
+// color_space_adjust gradients from the first conv's scatter buffer (include/rsu.h, rsu_color_adjust_bwd): 12 outputs, each a
+// 9 x Cout sum in a fixed order (lane-strided partials, then an LDS tree): one block of 12 x 64 threads
+__global__ void __launch_bounds__(768) k_color_adjust_bwd(const float* __restrict__ gx, const float* __restrict__ w1, float* __restrict__ dW0,
+                                                           float* __restrict__ db0, int Cout, float scale, int accumulate) {
+    __shared__ float red[12][64];
+    const int o = threadIdx.x >> 6, l = threadIdx.x & 63;  // o < 9: dW0[ci][cj] with o = 3*ci + cj; o >= 9: db0[cj]
+    const int cj = o < 9 ? o % 3 : o - 9;
+    float t = 0.f;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int co = l; co < Cout; co += 64) t += w1[(tap * 3 + cj) * Cout + co] * gx[(tap * 12 + o) * Cout + co];
+    red[o][l] = t;
+    __syncthreads();
+    if (l == 0) {
+        float r = 0.f;
+        for (int q = 0; q < 64; ++q) r += red[o][q];
+        r *= scale;
+        float* dst = o < 9 ? dW0 + o : db0 + (o - 9);
+        *dst = accumulate ? *dst + r : r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // momentum SGD (tf_aerial_images.py:116-121)
 // ---------------------------------------------------------------------------------------------
@@ -669,6 +690,10 @@ hipError_t ew_head(bool train, const void* act, const float* w, const float* b, 
     } else {
         hipLaunchKernelGGL(k_head<false>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, nullptr, prob, logits, nullptr, nullptr, npix, C, 0.f);
     }
+    return hipGetLastError();
+}
+hipError_t ew_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(k_color_adjust_bwd, dim3(1), dim3(768), 0, st, gx, w1, dW0, db0, Cout, scale, accumulate);
     return hipGetLastError();
 }
 hipError_t ew_momentum(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n, hipStream_t st) {

@@ -653,6 +653,13 @@ extern "C" int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, cons
     return RSU_OK;
 }
 static bool head_c_ok(int C) { return C >= 8 && C <= 512 && (C % 8) == 0 && ((C / 8) & (C / 8 - 1)) == 0; }
+extern "C" int rsu_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate,
+                                    rsu_stream_t stream) {
+    if (!gx || !w1 || !dW0 || !db0 || Cout < 1 || !(scale > 0.f)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_color_adjust_bwd(gx, w1, dW0, db0, Cout, scale, accumulate, (hipStream_t)stream));
+    return RSU_OK;
+}
+
 extern "C" int rsu_head_fwd(const void* act, const float* w, const float* b, float* prob, float* logits, long npix, int C,
                             rsu_stream_t stream) {
     if (!act || !w || !b || !prob || !head_c_ok(C) || npix < 1) return RSU_EINVAL;

@@ -491,17 +491,12 @@ class UNet:
         self._join_side()
         # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
         #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
-        def first_grads(kname, gx):
-            w1 = self.w[kname].reshape(9, 3, -1)
-            gxc = gx[:, :9, :].reshape(9, 3, 3, -1)
-            return torch.einsum("tjo,tijo->ij", w1, gxc), torch.einsum("tjo,tjo->j", w1, gx[:, 9:, :])
-        dw0, db0 = first_grads("conv_0/conv1/kernel", self.gfirst[0])
-        if self.dilated and L > 1:
-            dwd, dbd = first_grads("conv_dilut_0/atrous_conv1/kernel", self.gfirst[1])
-            dw0, db0 = dw0 + dwd, db0 + dbd
         inv_keep = float(np.float32(1.0) / np.float32(keep))
-        self.g["color_space_adjust/kernel"].copy_((dw0 * inv_keep).view(1, 1, 3, 3))
-        self.g["color_space_adjust/bias"].copy_(db0 * inv_keep)
+        gk, gb = self.g["color_space_adjust/kernel"], self.g["color_space_adjust/bias"]
+        call("rsu_color_adjust_bwd", _ptr(self.gfirst[0]), _ptr(self.w["conv_0/conv1/kernel"]), _ptr(gk), _ptr(gb), self.root, inv_keep, 0, st)
+        if self.dilated and L > 1:
+            call("rsu_color_adjust_bwd", _ptr(self.gfirst[1]), _ptr(self.w["conv_dilut_0/atrous_conv1/kernel"]), _ptr(gk), _ptr(gb), self.root,
+                 inv_keep, 1, st)
 
     # ------------------------------------------------------------------ optimizer
     def learning_rate(self, lr0):

@@ -213,6 +213,26 @@ def test_color_adjust_and_first_conv(dil, keep):
 
 
 # ------------------------------------------------------------------------------------------- pool
+@pytest.mark.parametrize("Cout,scale", [(64, 1.0), (16, 1.25), (72, 1.0)])
+def test_color_adjust_bwd_from_scatter_buffer(Cout, scale):
+    """rsu_color_adjust_bwd against the two sums of include/rsu.h in float64 (the formula itself is pinned against the oracle's
+    color_space_adjust gradients by test_color_adjust_and_first_conv and the whole-net gradient tests)."""
+    rng = np.random.RandomState(Cout)
+    gx = rng.randn(9, 12, Cout).astype(np.float32)
+    w1 = rng.randn(3, 3, 3, Cout).astype(np.float32)
+    w9 = w1.reshape(9, 3, Cout).astype(np.float64)
+    dW = np.einsum("tjo,tijo->ij", w9, gx[:, :9].reshape(9, 3, 3, Cout).astype(np.float64)) * scale
+    db = np.einsum("tjo,tjo->j", w9, gx[:, 9:].astype(np.float64)) * scale
+    dWd, dbd = torch.full((3, 3), 7.0, device=hu.DEV), torch.full((3,), 7.0, device=hu.DEV)
+    gxd, w1d = hu.dev_f32(gx), hu.dev_f32(w1)
+    call("rsu_color_adjust_bwd", hu.ptr(gxd), hu.ptr(w1d), hu.ptr(dWd), hu.ptr(dbd), Cout, scale, 0, hu.stream())
+    np.testing.assert_allclose(hu.host(dWd), dW, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(hu.host(dbd), db, rtol=2e-5, atol=2e-5)
+    call("rsu_color_adjust_bwd", hu.ptr(gxd), hu.ptr(w1d), hu.ptr(dWd), hu.ptr(dbd), Cout, scale, 1, hu.stream())  # accumulate
+    np.testing.assert_allclose(hu.host(dWd), 2 * dW, rtol=2e-5, atol=4e-5)
+    np.testing.assert_allclose(hu.host(dbd), 2 * db, rtol=2e-5, atol=4e-5)
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 12, 16, 64), (1, 30, 26, 16), (1, 9, 11, 8)])
 def test_maxpool_fwd_and_junction_bwd(N, H, W, C):
     rng = np.random.RandomState(H + C)
