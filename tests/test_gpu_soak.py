@@ -25,6 +25,11 @@ def test_c2_passes_with_dropout_and_small_net_are_bit_identical():
     assert soak_net.soak(150, bwd=True, L=3, root=32, P=100, B=2) == 0
 
 
+def test_c3_dilated_passes_are_bit_identical():
+    import soak_net
+    assert soak_net.soak(80, bwd=True, L=6, B=1, dilated=True) == 0   # dilated twins, three-source decoder convs, accumulate
+
+
 def test_short_training_runs_are_bit_identical():
     from road_segmentation_unet_amd.unet import UNet
 

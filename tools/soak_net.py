@@ -3,7 +3,7 @@
 every activation, activation gradient and weight gradient must be bit-identical to the first pass. Between two launches of
 one kernel the other kernels of the net run, so instruction caches, LDS contents and clocks differ from launch to launch --
 the conditions under which a rare register hazard shows (tools/soak_layers.py, one kernel back to back, does not provoke it).
-usage: python tools/soak_net.py [--reps 400] [--fwd-only] [--L 5 --root 64 --P 388 --B 4] [--keep 1.0]"""
+usage: python tools/soak_net.py [--reps 400] [--fwd-only] [--L 5 --root 64 --P 388 --B 4] [--keep 1.0] [--dilated]"""
 import argparse
 import os
 import sys
@@ -14,9 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from road_segmentation_unet_amd.unet import UNet  # noqa: E402
 
 
-def soak(reps, bwd=True, L=5, root=64, P=388, B=4, keep=1.0, max_report=5, verbose=True):
+def soak(reps, bwd=True, L=5, root=64, P=388, B=4, keep=1.0, max_report=5, verbose=True, dilated=False):
     """returns the number of passes that differed from the first one"""
-    net = UNet(L, root, False, B, P, seed=2018, training=True)
+    net = UNet(L, root, dilated, B, P, seed=2018, training=True)
     g = torch.Generator(device="cpu").manual_seed(7)
     net.x.copy_(torch.rand((B, net.S, net.S, 3), generator=g))
     net.labels.copy_((torch.rand((B, P, P), generator=g) < 0.2).to(torch.int64))
@@ -61,5 +61,6 @@ if __name__ == "__main__":
     ap.add_argument("--P", type=int, default=388)
     ap.add_argument("--B", type=int, default=4)
     ap.add_argument("--keep", type=float, default=1.0)
+    ap.add_argument("--dilated", action="store_true")
     a = ap.parse_args()
-    sys.exit(1 if soak(a.reps, not a.fwd_only, a.L, a.root, a.P, a.B, a.keep) else 0)
+    sys.exit(1 if soak(a.reps, not a.fwd_only, a.L, a.root, a.P, a.B, a.keep, dilated=a.dilated) else 0)
