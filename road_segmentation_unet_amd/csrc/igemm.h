@@ -46,7 +46,7 @@ struct IgFwdCfgInfo { int TN, TM, threads; };
 IgFwdCfgInfo igemm_fwd_cfg_info(int cfg);
 size_t igemm_fwd_lds_bytes(int cfg, int ntap, int npix_max);
 // second generation (persistent, counted-vmcnt pipeline; igemm_fwd2.hip)
-enum { IGF2_CFG_128x256 = 0, IGF2_CFG_64x512 = 1, IGF2_CFG_128x128 = 2, IGF2_CFG_64x256 = 3, /* 4, 5: retired 4-wave shapes */
+enum { IGF2_CFG_128x256 = 0, IGF2_CFG_64x512 = 1, IGF2_CFG_128x128 = 2, IGF2_CFG_64x256 = 3, IGF2_CFG_128x192 = 4, IGF2_CFG_64x384 = 5,
        IGF2_CFG_128x320 = 6, IGF2_CFG_64x640 = 7, IGF2_NCFG = 8 };
 IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg);
 int igemm_fwd2_max_pieces(int cfg, int ntap);

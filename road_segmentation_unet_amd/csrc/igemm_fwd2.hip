@@ -459,6 +459,16 @@ template <> struct Fwd2Cfg<IGF2_CFG_64x256> {
     static constexpr int na(int ntap) { return ntap == 1 ? 2 : 4; }
 };
 // five pixel fragments per wave (80 accumulator registers): a fifth fewer weight pieces and LDS reads per MFMA than 128x256
+// three pixel fragments per wave: between the 256/512- and the 128/256-pixel shapes, for layers whose tile count fills the last
+// round badly with either
+template <> struct Fwd2Cfg<IGF2_CFG_128x192> {
+    static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3;
+    static constexpr int na(int ntap) { return ntap == 1 ? 2 : 4; }
+};
+template <> struct Fwd2Cfg<IGF2_CFG_64x384> {
+    static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3;
+    static constexpr int na(int ntap) { return ntap == 1 ? 3 : 5; }
+};
 template <> struct Fwd2Cfg<IGF2_CFG_128x320> {
     static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 5;
     static constexpr int na(int ntap) { return ntap == 1 ? 3 : 5; }
@@ -482,6 +492,8 @@ IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg) {
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
         CASE(IGF2_CFG_64x256)
+        CASE(IGF2_CFG_128x192)
+        CASE(IGF2_CFG_64x384)
         CASE(IGF2_CFG_128x320)
         CASE(IGF2_CFG_64x640)
 #undef CASE
@@ -495,6 +507,8 @@ int igemm_fwd2_max_pieces(int cfg, int ntap) {
         CASE(IGF2_CFG_64x512)
         CASE(IGF2_CFG_128x128)
         CASE(IGF2_CFG_64x256)
+        CASE(IGF2_CFG_128x192)
+        CASE(IGF2_CFG_64x384)
         CASE(IGF2_CFG_128x320)
         CASE(IGF2_CFG_64x640)
 #undef CASE
@@ -540,6 +554,8 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int gx, in
         case IGF2_CFG_64x512: return launch2_cfg<IGF2_CFG_64x512>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x128: return launch2_cfg<IGF2_CFG_128x128>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x256: return launch2_cfg<IGF2_CFG_64x256>(ntap, p, gx, gy, st);
+        case IGF2_CFG_128x192: return launch2_cfg<IGF2_CFG_128x192>(ntap, p, gx, gy, st);
+        case IGF2_CFG_64x384: return launch2_cfg<IGF2_CFG_64x384>(ntap, p, gx, gy, st);
         case IGF2_CFG_128x320: return launch2_cfg<IGF2_CFG_128x320>(ntap, p, gx, gy, st);
         case IGF2_CFG_64x640: return launch2_cfg<IGF2_CFG_64x640>(ntap, p, gx, gy, st);
     }

@@ -353,7 +353,8 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         // measured per-MAC cost of the shapes relative to 128x256: two pixel fragments per wave read 6 LDS fragments per 8 MFMAs
         // and stream twice the weight pieces per MFMA (x1.5 priced: it also covers their shorter stages); five fragments per wave are a little cheaper (x0.96)
         const int ptw = ci.TM / 16 / (ci.threads / 64 / (ci.TN / 64));
-        const double eff = ptw <= 2 ? (double)env_int("RSU_PLAN_PT2_PCT", 150) / 100.0 : (ptw >= 5 ? 0.96 : 1.0);
+        const double eff = ptw <= 2 ? (double)env_int("RSU_PLAN_PT2_PCT", 150) / 100.0
+                                    : (ptw == 3 ? (double)env_int("RSU_PLAN_PT3_PCT", 120) / 100.0 : (ptw >= 5 ? 0.96 : 1.0));
         const double cost = nrounds * ((double)ci.TM * ci.TN * eff + ovh);
         if (cost < best_cost) {
             best_cost = cost;

@@ -16,7 +16,7 @@ from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
 from tests import hiputil as hu  # noqa: E402
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 6, 7])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7])
 def forced_cfg(request):
     old = os.environ.get("RSU_FWD2_CFG")
     os.environ["RSU_FWD2_CFG"] = str(request.param)
@@ -79,7 +79,7 @@ def test_dilated_three_source_and_accumulate_every_shape(forced_cfg):
     a = hu.q(_rand(rng, N, h + 12, w + 10, 48))
     bsrc = hu.q(_rand(rng, N, h + 6, w + 4, 16))
     c = hu.q(_rand(rng, N, h, w, 64))
-    Cout = 128 if forced_cfg in (0, 2, 6) else 64
+    Cout = 128 if forced_cfg in (0, 2, 4, 6) else 64
     W = _rand(rng, 3, 3, 128, Cout, scale=0.05)
     bias = _rand(rng, Cout, scale=0.1)
     ad, bd_, cd, biasd = hu.dev_bf16(a), hu.dev_bf16(bsrc), hu.dev_bf16(c), hu.dev_f32(bias)

@@ -99,9 +99,9 @@ def main():
         for op in ops:
             for cfg in (cfgs if op != "wg" else [-1]):
                 if cfg >= 0:
-                    os.environ["RSU_FWD_CFG"] = str(cfg)
+                    os.environ["RSU_FWD2_CFG"] = str(cfg)
                 else:
-                    os.environ.pop("RSU_FWD_CFG", None)
+                    os.environ.pop("RSU_FWD2_CFG", None)
                 try:
                     if op == "fwd":
                         t = timeit(lambda: call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, st))
@@ -115,7 +115,7 @@ def main():
                     tot[(op, cfg)] = tot.get((op, cfg), 0.0) + t
                 except Exception as ex:
                     line += " %s[%d] n/a |" % (op, cfg)
-        os.environ.pop("RSU_FWD_CFG", None)
+        os.environ.pop("RSU_FWD2_CFG", None)
         print(line, flush=True)
     print("totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()})
 
