@@ -54,6 +54,12 @@ int rsu_last_hip_error(void);
  * single-device): a data-parallel host may leave some CUs to the RCCL channel workgroups of an overlapped gradient all-reduce. */
 int rsu_set_cu_budget(int ncu);
 int rsu_get_cu_budget(void);
+/* Tile-shape choice of the conv launches by measurement (default on; RSU_AUTOTUNE=0 in the environment also disables it): the
+ * first launch of a new geometry times every admissible tile shape on an idle device (it synchronises the device once) and
+ * later launches of that geometry use the fastest. All shapes give bit-identical results. rsu_autotune_entries: geometries
+ * tuned so far. */
+int rsu_set_autotune(int on);
+int rsu_autotune_entries(void);
 /* unet.py:100-115 input_size_needed(output_size, num_layers). RSU_EINVAL where the reference asserts. */
 int rsu_input_size_needed(int output_size, int num_layers, int* input_size);
 

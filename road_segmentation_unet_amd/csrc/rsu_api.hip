@@ -1,9 +1,12 @@
 // extern "C" entry points of librsu_hip.so (declared in include/rsu.h): argument checks, tile planning,
 // kernel-configuration choice and launches. No torch types, no hidden allocations: every buffer is the
 // caller's; the only library-owned device memory is a 4-KiB page of zeros used for out-of-window reads.
+#include <array>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "../../include/rsu.h"
 #include "elementwise.h"
@@ -43,6 +46,21 @@ extern "C" int rsu_set_cu_budget(int ncu) {
     return RSU_OK;
 }
 extern "C" int rsu_get_cu_budget(void) { return g_cu_budget.load(); }
+// Tile-shape choice of the persistent conv launches by measurement. Every shape computes bit-identical results (the reduction
+// order of an output element does not depend on the tile it lies in; tests/test_gpu_cfg_matrix.py), so the choice only affects
+// speed. With tuning on, the first launch of a new (geometry, flags, CU budget) times every admissible shape on an idle device
+// and remembers the fastest; later launches look it up. Off: the planner's cost model decides (as does RSU_FWD2_CFG >= 0).
+static std::atomic<int> g_autotune{1};
+static std::mutex g_tune_mutex;
+static std::map<std::array<int, 16>, int> g_tuned;
+extern "C" int rsu_set_autotune(int on) {
+    g_autotune.store(on ? 1 : 0);
+    return RSU_OK;
+}
+extern "C" int rsu_autotune_entries(void) {
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    return (int)g_tuned.size();
+}
 
 extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input_size) {
     // unet.py:100-115: (L-1) x { assert even; o = (o+4)/2 }, (L-1) x { o = (o+4)*2 }, +4
@@ -381,7 +399,20 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     Fwd2Plan pl2;
     int ktot = 0;
     for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * ntap;
-    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, env_int("RSU_FWD2_CFG", -1), pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0);
+    const int env_cfg = env_int("RSU_FWD2_CFG", -1);
+    const bool shared_chip = pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0;
+    // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
+    const bool tunable = gen2 && env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
+    std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc, (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0),
+                                ostride, g_cu_budget.load()};
+    int tuned_cfg = -1;
+    bool tune_now = false;
+    if (tunable) {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        auto it = g_tuned.find(tkey);
+        if (it != g_tuned.end()) tuned_cfg = it->second; else tune_now = true;
+    }
+    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip);
     if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -425,6 +456,47 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                     N, Ho, Wo, Cout, ntap, pad, pl2.cfg, ci.TN, ci.TM, pl2.g.SW, pl2.g.nstrips, pl2.g.tiles_per_strip, pl2.g.npix_max, tiles,
                     pl2.grid_x, rounds, (double)N * Ho * Wo / ((double)tiles * ci.TM),
                     (double)N * Ho * Wo * Cout / ((double)rounds * pl2.grid_x * ci.TM * ci.TN));
+        }
+        if (tune_now) {
+            // time every admissible shape of the same channel-block width (1 untimed + 3 timed launches each, device idle; the
+            // launches all write the same values, so the output is valid whichever ran last)
+            const int tn_model = igemm_fwd2_cfg_info(pl2.cfg).TN;
+            hipEvent_t e0, e1;
+            HIP_CHECK_RET(hipEventCreate(&e0));
+            HIP_CHECK_RET(hipEventCreate(&e1));
+            HIP_CHECK_RET(hipDeviceSynchronize());
+            float best_ms = 1e30f;
+            int best_cfg = pl2.cfg;
+            for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
+                if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
+                Fwd2Plan pc;
+                if (!plan_fwd2(pc, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
+                IgFwdParams pt = p;
+                pt.ncob = pc.ncob;
+                pt.g = pc.g;
+                pt.lsw = pc.lsw;
+                float ms_min = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    HIP_CHECK_RET(hipEventRecord(e0, st));
+                    HIP_CHECK_RET(igemm_fwd2_launch(pc.cfg, ntap, pt, pc.grid_x, gy, st));
+                    HIP_CHECK_RET(hipEventRecord(e1, st));
+                    HIP_CHECK_RET(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0 && ms < ms_min) ms_min = ms;
+                }
+                if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] cfg%d %.1f us\n", cfg, ms_min * 1e3f);
+                if (ms_min < best_ms) {
+                    best_ms = ms_min;
+                    best_cfg = cfg;
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] model cfg%d -> measured cfg%d\n", pl2.cfg, best_cfg);
+            std::lock_guard<std::mutex> lk(g_tune_mutex);
+            g_tuned[tkey] = best_cfg;
+            return RSU_OK;
         }
         HIP_CHECK_RET(igemm_fwd2_launch(pl2.cfg, ntap, p, pl2.grid_x, gy, st));
         return RSU_OK;

@@ -69,3 +69,31 @@ def test_two_stream_schedule_does_not_change_the_numbers():
 
     a, b = run(False), run(True)
     assert torch.equal(a, b)
+
+
+def test_measured_tile_shapes_do_not_change_the_numbers():
+    """rsu_set_autotune: the tile shapes picked by measurement give the same bits as the cost model's choice."""
+    from road_segmentation_unet_amd._lib import call, lib
+    from road_segmentation_unet_amd.unet import UNet
+
+    def run(tune):
+        call("rsu_set_autotune", 1 if tune else 0)
+        m = UNet(4, 32, False, 2, 204, seed=5, training=True)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        for _ in range(3):
+            m.x.copy_(torch.rand((2, m.S, m.S, 3), generator=g))
+            m.labels.copy_((torch.rand((2, 204, 204), generator=g) < 0.2).to(torch.int64))
+            m.forward_device(keep=0.9)
+            m.backward_device(1.0 / (2 * 204 * 204))
+            m.apply_momentum(0.01, 0.9)
+        torch.cuda.synchronize()
+        return m.flat_w.clone()
+
+    try:
+        n0 = lib().rsu_autotune_entries()
+        a = run(True)
+        assert lib().rsu_autotune_entries() > n0
+        b = run(False)
+    finally:
+        call("rsu_set_autotune", 1)
+    assert torch.equal(a, b)
