@@ -81,8 +81,16 @@ igemm_fwd2_kernel(const IgFwdParams p) {
     const int ooffy = ph >> 1, ooffx = ph & 1;
 
     // ---- this workgroup's tile list: fixed channel block, m-tiles first, first+stride, ...
-    const int cob = blockIdx.x % p.ncob;
-    const int tile0 = blockIdx.x / p.ncob, tstride = gridDim.x / p.ncob;
+    // XCD-aware numbering: blocks whose ids agree modulo 8 are observed to share an XCD (and its L2). Renumber so that such a group
+    // owns a contiguous run of (pixel tile, channel block) pairs: the channel blocks of one pixel tile read the same halo, and
+    // neighbouring tiles overlap in theirs. Speed only -- any placement computes the same values. (dbg bit 6: plain numbering)
+    int vid = blockIdx.x;
+    if (!(p.dbg & 64)) {
+        const int q = gridDim.x >> 3, r = gridDim.x & 7, x = vid & 7;
+        vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
+    }
+    const int cob = vid % p.ncob;
+    const int tile0 = vid / p.ncob, tstride = gridDim.x / p.ncob;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     const int ntile_m = p.N * tpi;
     const int my_tiles = tile0 < ntile_m ? (ntile_m - tile0 + tstride - 1) / tstride : 0;
