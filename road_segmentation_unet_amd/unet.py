@@ -346,12 +346,15 @@ class UNet:
         for i in range(L):
             last = i == L - 1
             if self.dilated and not last:
-                if i == 0:
-                    call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_dilut_0/atrous_conv1/kernel", "fwd"]),
-                         _ptr(self.w["conv_dilut_0/atrous_conv1/bias"]), _ptr(a["d1_0"]), B, h, h, self.root, 2, st)
-                else:
-                    self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
-                self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
+                # the dilated twin block (unet.py:32-39) reads the level's input and feeds only a decoder skip: it runs on the second
+                # stream beside the main block (joined in front of the decoder)
+                with UNet._Side(self):
+                    if i == 0:
+                        call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_dilut_0/atrous_conv1/kernel", "fwd"]),
+                             _ptr(self.w["conv_dilut_0/atrous_conv1/bias"]), _ptr(a["d1_0"]), B, h, h, self.root, 2, self._stream())
+                    else:
+                        self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
+                    self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
             if i == 0:
                 call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_0/conv1/kernel", "fwd"]), _ptr(self.w["conv_0/conv1/bias"]),
                      _ptr(a["c1_0"]), B, h, h, self.root, 1, st)
@@ -363,6 +366,8 @@ class UNet:
                 call("rsu_maxpool2x2_fwd", _ptr(c2), _ptr(a["pool_%d" % i]), B, h - 4, h - 4, c2.shape[3], keep, self.dropout_key(i + 1), st)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
+        if self.dilated:
+            self._join_side()
         for i in range(L - 1):
             j, lvl = L + i, L - 2 - i
             up = a["up_%d" % i]
