@@ -130,9 +130,116 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
     static_assert((NPL * TMK / 8) % NW == 0, "F pieces per wave must be a constant");
     constexpr int NFW = NPL * TMK / 8 / NW;
-    // `ln` = lane id made opaque per call: keeps the compiler from hoisting the per-piece address arithmetic out of the tile
-    // loop (where it would sit in ~25 spilled VGPRs and come back through scratch loads + vmcnt(0) every tile)
+    // Per-lane source offsets of the staging pieces do not depend on the tile (tiles are aligned): they are computed once (NFW + up to
+    // 5 VGPRs) and an interior tile -- every pixel of the F tile and of the S halo inside the image -- issues its pieces with no
+    // per-lane arithmetic at all (the address math was ~60 % of the kernel's VALU instructions, all of them in front of a DMA
+    // instruction the wave's MFMAs wait behind). Edge tiles (last strip / last rows) redo the validity tests per lane; `ln` = lane
+    // id made opaque there keeps that arithmetic from being hoisted out of the tile loop into spilled registers.
+    // (Measured: +5-8 % on the layers that run the two-wave-group shapes; the 128x64 shape, which has no VGPRs to spare for the
+    // cache, lost 4-7 % with it and keeps computing its offsets per tile.)
+    constexpr bool CACHED = KG == 2;
+    constexpr int NSW_MAX = 5;
+    unsigned fvo[NFW], svo[NSW_MAX];
+#pragma unroll
+    for (int q = 0; q < (CACHED ? NFW : 0); ++q) {
+        const int j = q * NW + wave;
+        const int pl = j / (TMK / 8), jj = j - pl * (TMK / 8);
+        const int ml = jj * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (((ml >> 1) & 3) << 1);
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        fvo[q] = (cfb * CFB + pl * 64 + c * 8 < p.Cf) ? (unsigned)(((ty * p.Wf + tx) * p.Cf + pl * 64 + c * 8) * 2) : RSU_SENT;
+    }
+#pragma unroll
+    for (int q = 0; q < (CACHED ? NSW_MAX : 0); ++q) {
+        const int j = q * NW + wave;
+        const int hp = j * PPP + lane / LPP;
+        const int pc = lane % LPP;
+        const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
+        const int rr = div_magic(hp, p.g.inv_CW);
+        const int cc = hp - rr * CW;
+        svo[q] = (q < nsw && hp < p.g.npix_max && csb * CSB + c * 8 < p.S.C) ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
+    }
+    const int halo_rows = div_magic(p.g.npix_max - 1, p.g.inv_CW) + 1;  // rows of the staged S halo tile
     auto issue = [&](const Tile& T, int buf) {
+        if constexpr (CACHED) {
+        // F tile: TMK pixels x CFB channels as planes of 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
+        {
+            const __amdgpu_buffer_rsrc_t rf = mk(p.F);
+            const unsigned soffF = (unsigned)((((long)(T.n * p.Hf + T.y0) * p.Wf + T.x0) * p.Cf + cfb * CFB) * 2);
+            const bool inside = (T.y0 + TR <= p.Hf) && (T.x0 + SW <= p.Wf);  // wave-uniform
+            if (inside) {
+#pragma unroll
+                for (int q = 0; q < NFW; ++q) bdma16(rf, fvo[q], soffF, (void*)(lds + buf * FBUF + (q * NW + wave) * 1024));
+            } else {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int q = 0; q < NFW; ++q) {
+                    const int j = q * NW + wave;
+                    const int pl = j / (TMK / 8), jj = j - pl * (TMK / 8);
+                    const int ml = jj * 8 + (ln >> 3);
+                    const int ty = ml >> lsw, tx = ml & (SW - 1);
+                    const bool ok = (T.y0 + ty < p.Hf) && (T.x0 + tx < p.Wf);
+                    unsigned vo;
+                    if constexpr (CACHED) {
+                        vo = fvo[q];
+                    } else {
+                        const int c = (ln & 7) ^ (((ml >> 1) & 3) << 1);
+                        vo = (cfb * CFB + pl * 64 + c * 8 < p.Cf) ? (unsigned)(((ty * p.Wf + tx) * p.Cf + pl * 64 + c * 8) * 2) : RSU_SENT;
+                    }
+                    bdma16(rf, ok ? vo : RSU_SENT, soffF, (void*)(lds + buf * FBUF + j * 1024));
+                }
+            }
+        }
+        // S halo tile
+        {
+            const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
+            const int iy0 = T.y0 * p.stride, ix0 = T.x0 * p.stride;
+            const unsigned soffS = (unsigned)((((long)(T.n * p.S.H + iy0 + p.S.oy) * p.S.W + ix0 + p.S.ox) * p.S.C + csb * CSB) * 2);
+            const bool inside = (iy0 + halo_rows <= Hs) && (ix0 + CW <= Ws);  // wave-uniform
+            if (inside) {
+#pragma unroll
+                for (int q = 0; q < NSW_MAX; ++q)
+                    if (q < nsw) bdma16(rs, svo[q], soffS, (void*)(lds + s_base + buf * SBUF + (q * NW + wave) * 1024));
+            } else {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int q = 0; q < NSW_MAX; ++q) {  // pieces past the halo tile (hp >= npix_max) carry RSU_SENT already or are never read
+                    if (q >= nsw) break;
+                    const int j = q * NW + wave;
+                    const int hp = j * PPP + ln / LPP;
+                    const int rr = div_magic(hp, p.g.inv_CW);
+                    const int cc = hp - rr * CW;
+                    const bool ok = (iy0 + rr < Hs) && (ix0 + cc < Ws);
+                    unsigned vo;
+                    if constexpr (CACHED) {
+                        vo = svo[q];
+                    } else {
+                        const int pc = ln % LPP;
+                        const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
+                        vo = (hp < p.g.npix_max && csb * CSB + c * 8 < p.S.C) ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
+                    }
+                    bdma16(rs, ok ? vo : RSU_SENT, soffS, (void*)(lds + s_base + buf * SBUF + j * 1024));
+                }
+            }
+            if (nsw > NSW_MAX) {  // big halo tiles of the two-buffer ring: the pieces beyond the cached ones, in full
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                for (int q = NSW_MAX; q < nsw; ++q) {
+                    const int j = q * NW + wave;
+                    const int hp = j * PPP + ln / LPP;
+                    const int pc = ln % LPP;
+                    const int c = (LPP == 8) ? (pc ^ (((hp >> 1) & 3) << 1)) : pc;
+                    const int rr = div_magic(hp, p.g.inv_CW);
+                    const int cc = hp - rr * CW;
+                    const bool ok = (hp < p.g.npix_max) && (iy0 + rr < Hs) && (ix0 + cc < Ws) && (csb * CSB + c * 8 < p.S.C);
+                    const unsigned voff = ok ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
+                    bdma16(rs, voff, soffS, (void*)(lds + s_base + buf * SBUF + j * 1024));
+                }
+            }
+        }
+        } else {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         // F tile: TMK pixels x CFB channels as planes of 64 channels, 8 pixels per piece; rows/cols beyond the image come back as zeros
@@ -167,6 +274,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                 const unsigned voff = ok ? (unsigned)(((rr * p.S.W + cc) * p.S.C + c * 8) * 2) : RSU_SENT;
                 bdma16(rs, voff, soffS, (void*)(lds + s_base + buf * SBUF + j * 1024));
             }
+        }
         }
     };
 
