@@ -77,7 +77,7 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     for (int a = 0; a < CFT; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ... and the column sums of S over every tap (ones x S): the bias gradient of the transposed conv (S = dy, taps = the four
     // disjoint output phases), in the waves of cf block 0
-    const bool do_sbias = (p.sbslab != nullptr) && (cfb == 0) && (wcf == 0);
+    const bool do_sbias = NTAP < 9 && (p.sbslab != nullptr) && (cfb == 0) && (wcf == 0);  // (only the transposed conv asks for them: no per-step branch in the 3x3 kernels)
     f32x4 accs[CST];
 #pragma unroll
     for (int b = 0; b < CST; ++b) accs[b] = f32x4{0.f, 0.f, 0.f, 0.f};
