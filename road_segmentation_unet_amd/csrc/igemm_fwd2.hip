@@ -248,6 +248,28 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
+        if (!p.mask_src && !p.accumulate) {
+            // the common case (forward, backward-data without a ReLU mask) without a single branch per store: ReLU as a packed int16
+            // max against 0 or, switched off, against the most negative int16 (bf16 sign bit == int16 sign bit)
+            typedef __attribute__((ext_vector_type(2))) short s2;
+            const short fl = p.relu ? (short)0 : (short)-32768;
+            const s2 floor2 = {fl, fl};
+#pragma unroll
+            for (int e = 0; e < NST; ++e) {
+                const int pt = e / (CT / 2), pp = e % (CT / 2);
+                const unsigned voff = out_voff(T, e);
+                u32x4 r;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
+                    const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
+                    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                    r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                }
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voff), "s"(orsrc), "s"(sbase) : "memory");
+            }
+            return;
+        }
         // NST stores in batches of four: the mask / accumulate loads of a batch are requested together (one memory latency per
         // batch instead of one per store); larger batches would need more than the 16-32 VGPRs that are free here
         constexpr int EB = NST % 4 == 0 ? 4 : 2;
