@@ -119,13 +119,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RSU_BENCH_BACKEND=gloo (tests only): the same multi-rank code path with the ranks sharing whatever GPUs exist -- RCCL
+    # refuses two ranks on one device, and the GPU test box has one
+    backend = os.environ.get("RSU_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu_index))
+        else:
+            dist.init_process_group(backend)
+    dev = "cuda:%d" % gpu_index
+    torch.cuda.set_device(gpu_index)
 
     L, root, P, B = args.num_layers, args.root_size, args.patch_size, args.batch_per_gpu
     S = input_size_needed(P, L)

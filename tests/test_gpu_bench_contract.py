@@ -29,3 +29,26 @@ def test_bench_prints_one_contract_line():
     assert r["traffic"] is None or r["traffic"] > 1e6
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "patches/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """The driver launches bench.py under torch.distributed.run for N > 1; here the same launch with two ranks on the one GPU
+    of the test box (gloo instead of RCCL): sharded step, schedule tuning, MAX-over-ranks timing, one line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RSU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no_cpu_baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 20 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    ex = d["config"]["dp_exchange"]
+    assert ex["conv_cu_budget"] in (256, 240, 224, 208) and len(ex["tuned_ms_per_step"]) == 5
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None or d["cpu_baseline"]
