@@ -148,6 +148,9 @@ def main():
         m.on_grads = bucketer.ready
     lr, mu = 0.01, 0.9
 
+    # one priming step, untimed and not counted in --warmup: the first launch of every conv geometry measures the tile shapes
+    # (rsu_set_autotune); with --warmup 0 that would otherwise land in the timed region
+    run_step(m, bucketer, lr, mu)
     dp_tune = None
     if bucketer is not None and "RSU_DP_OVERLAP" not in os.environ:
         # untimed: measure both gradient-exchange schedules on this node and keep the faster one (dist.tune_overlap)
