@@ -56,7 +56,7 @@ int rsu_set_cu_budget(int ncu);
 int rsu_get_cu_budget(void);
 /* Tile-shape choice of the conv launches by measurement (default on; RSU_AUTOTUNE=0 in the environment also disables it): the
  * first launch of a new geometry times every admissible tile shape on an idle device (it synchronises the device once) and
- * later launches of that geometry use the fastest. All shapes give bit-identical results. rsu_autotune_entries: geometries
+ * later launches of that geometry use the fastest (if it beats the cost model's choice by 3 %). All shapes give bit-identical results. rsu_autotune_entries: geometries
  * tuned so far. */
 int rsu_set_autotune(int on);
 int rsu_autotune_entries(void);

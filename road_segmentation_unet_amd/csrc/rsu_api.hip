@@ -458,14 +458,14 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                     (double)N * Ho * Wo * Cout / ((double)rounds * pl2.grid_x * ci.TM * ci.TN));
         }
         if (tune_now) {
-            // time every admissible shape of the same channel-block width (1 untimed + 3 timed launches each, device idle; the
+            // time every admissible shape of the same channel-block width (1 untimed + 5 timed launches each, fastest counts, device idle; the
             // launches all write the same values, so the output is valid whichever ran last)
             const int tn_model = igemm_fwd2_cfg_info(pl2.cfg).TN;
             hipEvent_t e0, e1;
             HIP_CHECK_RET(hipEventCreate(&e0));
             HIP_CHECK_RET(hipEventCreate(&e1));
             HIP_CHECK_RET(hipDeviceSynchronize());
-            float best_ms = 1e30f;
+            float best_ms = 1e30f, model_ms = 1e30f;
             int best_cfg = pl2.cfg;
             for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
                 if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
@@ -476,7 +476,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
                 float ms_min = 1e30f;
-                for (int rep = 0; rep < 4; ++rep) {
+                for (int rep = 0; rep < 6; ++rep) {
                     HIP_CHECK_RET(hipEventRecord(e0, st));
                     HIP_CHECK_RET(igemm_fwd2_launch(pc.cfg, ntap, pt, pc.grid_x, gy, st));
                     HIP_CHECK_RET(hipEventRecord(e1, st));
@@ -486,11 +486,15 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                     if (rep > 0 && ms < ms_min) ms_min = ms;
                 }
                 if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] cfg%d %.1f us\n", cfg, ms_min * 1e3f);
+                if (cfg == pl2.cfg) model_ms = ms_min;
                 if (ms_min < best_ms) {
                     best_ms = ms_min;
                     best_cfg = cfg;
                 }
             }
+            // hysteresis: a shape replaces the cost model's choice only when it measured at least 3 % faster (one noisy sample must
+            // not pin a slow shape for the rest of the run)
+            if (best_ms > 0.97f * model_ms) best_cfg = pl2.cfg;
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] model cfg%d -> measured cfg%d\n", pl2.cfg, best_cfg);
