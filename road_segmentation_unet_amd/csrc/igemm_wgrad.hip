@@ -71,7 +71,9 @@ igemm_wgrad_kernel(const IgWgradParams p) {
             for (int b = 0; b < CST; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // BiasAddGrad rides along: sum_pix F[pix][cf] = F^T x ones, one extra MFMA per k-step in the waves of cs block 0
-    const bool do_bias = (p.bslab != nullptr) && (csb == 0) && (wcs == 0);
+    // (which cs wave of a cf row carries them is free -- all see the same F fragments: pick different SIMDs for the different cf rows /
+    // wave groups, wave w runs on SIMD w % 4; with wcs == 0 everywhere both bias waves sat on SIMD 0: 80 MFMAs per k-step against 72)
+    const bool do_bias = (p.bslab != nullptr) && (csb == 0) && (wcs == (wcf + kgrp) % WCS);
     f32x4 accb[CFT];
 #pragma unroll
     for (int a = 0; a < CFT; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -401,8 +403,13 @@ igemm_wgrad_kernel(const IgWgradParams p) {
                 for (int a = 0; a < CFT; ++a)
 #pragma unroll
                     for (int b = 0; b < CST; ++b) red[((t * CFT + a) * CST + b) * (WCF * WCS * 64) + slot] = acc[t][a][b];
+            // bias sums: the wave that carries them in this group (a different cs wave than in group 0, see do_bias) parks them in the
+            // slot of group 0's bias wave of the same cf row
+            if (wcs == (wcf + 1) % WCS) {
+                const int slot_b = (wcf * WCS + wcf % WCS) * 64 + lane;
 #pragma unroll
-            for (int a = 0; a < CFT; ++a) red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot] = accb[a];
+                for (int a = 0; a < CFT; ++a) red[((NTAP * CFT + a) * CST) * (WCF * WCS * 64) + slot_b] = accb[a];
+            }
             if (NTAP < 9) {  // (the 9-tap hand-off already fills the 160 KiB; only the transposed conv carries S sums)
 #pragma unroll
                 for (int b = 0; b < CST; ++b) red[((NTAP * CFT + CFT) * CST + b) * (WCF * WCS * 64) + slot] = accs[b];
