@@ -227,8 +227,10 @@ def main():
                    "step_tflops_algorithmic": tot_fl * world * args.steps / dt / 1e12, "loss": loss,
                    "dp_exchange": (None if bucketer is None else
                                    {"overlapped_buckets": bool(bucketer.overlap), "conv_cu_budget": lib().rsu_get_cu_budget(),
+                                    "min_bucket_MB": bucketer.min_bucket * 4 >> 20,
                                     "tuned_ms_per_step": None if dp_tune is None else {
-                                        "%s/%dcu" % ("overlapped" if k[0] else "single", k[1]): v for k, v in dp_tune["ms"].items()}})},
+                                        "%s/%dcu/%dMB" % ("overlapped" if k[0] else "single", k[1], k[2] * 4 >> 20): v
+                                        for k, v in dp_tune["ms"].items()}})},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "kernel": "3x3 conv MFMA kernels: igemm_fwd (fwd, bwd-data) + igemm_wgrad",

@@ -83,7 +83,9 @@ class GradBucketer:
         self.pending = []
 
 
-EXCHANGE_CANDIDATES = ((True, 256), (True, 240), (True, 224), (True, 208), (False, 256))  # (overlapped buckets?, CU budget of the conv launches)
+# (overlapped buckets?, CU budget of the conv launches, smallest bucket in elements: 4 MB / 32 MB of fp32)
+EXCHANGE_CANDIDATES = ((True, 256, 1 << 20), (True, 256, 1 << 23), (True, 240, 1 << 23), (True, 224, 1 << 23), (True, 208, 1 << 23),
+                       (False, 256, 1 << 20))
 
 
 def tune_overlap(bucketer, step, trials=3, candidates=EXCHANGE_CANDIDATES, set_cu_budget=None):
@@ -92,18 +94,22 @@ def tune_overlap(bucketer, step, trials=3, candidates=EXCHANGE_CANDIDATES, set_c
     CUs (RCCL's channel workgroups and a persistent conv workgroup cannot share a CU: with all 256 taken, a conv launch that
     starts while an all-reduce is resident waits for CUs and roughly doubles), or one all-reduce after backward -- and the
     candidate with the smallest max-over-ranks time stays selected (every rank sees the same reduced timings, so all agree).
+    Small buckets start the exchange earlier, large ones mean fewer collective launches and bigger per-link messages on the
+    point-to-point xGMI links: both sizes are tried.
     Which one wins depends on the node at hand, which no single-GPU run can tell.
     set_cu_budget: callable(int) (the library's rsu_set_cu_budget); None = budgets other than 256 are skipped.
-    Returns {"overlap": bool, "cu_budget": int, "ms": {(overlap, budget): ms_per_step}}."""
+    Returns {"overlap": bool, "cu_budget": int, "min_bucket": int, "ms": {(overlap, budget, min_bucket): ms_per_step}}."""
     import time
     if bucketer is None or bucketer.world == 1:
-        return {"overlap": bool(bucketer.overlap) if bucketer is not None else False, "cu_budget": 256, "ms": {}}
+        return {"overlap": bool(bucketer.overlap) if bucketer is not None else False, "cu_budget": 256,
+                "min_bucket": bucketer.min_bucket if bucketer is not None else 0, "ms": {}}
     dev = bucketer.flat.device
     timings = {}
-    for mode, budget in candidates:
+    for mode, budget, min_bucket in candidates:
         if budget != 256 and set_cu_budget is None:
             continue
         bucketer.overlap = mode
+        bucketer.min_bucket = min_bucket
         if set_cu_budget is not None:
             set_cu_budget(budget)
         step()  # settle (stream creation, RCCL channel setup for this message pattern)
@@ -117,9 +123,10 @@ def tune_overlap(bucketer, step, trials=3, candidates=EXCHANGE_CANDIDATES, set_c
             torch.cuda.synchronize(dev)
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=bucketer.group)
-        timings[(mode, budget)] = float(t.item()) / trials * 1e3
+        timings[(mode, budget, min_bucket)] = float(t.item()) / trials * 1e3
     best = min(timings, key=lambda k: (timings[k], not k[0], -k[1]))
     bucketer.overlap = best[0]
+    bucketer.min_bucket = best[2]
     if set_cu_budget is not None:
         set_cu_budget(best[1])
-    return {"overlap": best[0], "cu_budget": best[1], "ms": timings}
+    return {"overlap": best[0], "cu_budget": best[1], "min_bucket": best[2], "ms": timings}

@@ -70,8 +70,8 @@ def _worker(rank, world, port, q):
         budgets = []
         tuned = tune_overlap(tb, step, trials=2, set_cu_budget=budgets.append)
         step()
-        ok4 = (bool((tflat == sum(range(1, world + 1))).all()) and set(tuned["ms"]) == {(True, 256), (True, 240), (True, 224), (True, 208), (False, 256)}
-               and tuned["overlap"] == tb.overlap and budgets[-1] == tuned["cu_budget"])
+        ok4 = (bool((tflat == sum(range(1, world + 1))).all()) and len(tuned["ms"]) == 6 and all(len(k) == 3 for k in tuned["ms"])
+               and tuned["overlap"] == tb.overlap and budgets[-1] == tuned["cu_budget"] and tb.min_bucket == tuned["min_bucket"])
         q.put((rank, ok1, ok2, ok3 and ok4, err, list(map(int, mine)), (bool(tuned["overlap"]), tuned["cu_budget"])))
     finally:
         dist.destroy_process_group()
