@@ -1,0 +1,185 @@
+// Probe (developer tool, GPU box): what a SIMD's matrix pipe sustains under the wave arrangements the conv kernels use.
+//   hipcc --offload-arch=gfx950 -O3 -o probes/probe_mfma_rate probes/probe_mfma_rate.hip && probes/probe_mfma_rate
+// Every variant runs ITER rounds of NM v_mfma_f32_16x16x32_bf16 (or NM/2 32x32x16) per wave on independent accumulators and
+// reports shader cycles (s_memtime) per round for wave 0 of block 0, plus the ideal (16 cycles per 16x16x32 MFMA per SIMD).
+//   mode 0: free-running, no barrier           mode 1: one s_barrier per round, all waves multiply together
+//   mode 2: ping-pong: groups G0 = waves 0-3, G1 = waves 4-7 alternate M rounds and idle rounds (two barriers per round)
+//   mode 3: ping-pong with NR ds_read_b128 in the idle round         mode 4: as 3 plus ND LDS-DMA pieces in the idle round
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <int MODE, int NM, int NR, int ND, bool BIG, bool AGPR>
+__global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsigned long long* cyc, int iters, int nthreads_active) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // operands: random-ish data from memory
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fa[i] = src[(threadIdx.x * 8 + i) & 4095];
+        fb[i] = src[(threadIdx.x * 8 + 4 + i) & 4095];
+    }
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((__attribute__((address_space(3))) bf16x8*)lds)[i & 4095] = src[i & 4095];
+    __syncthreads();
+    constexpr int NACC = BIG ? NM / 2 : NM;
+    f32x4 acc[BIG ? 1 : NM];
+    f32x16 accb[BIG ? NM / 2 : 1];
+    if constexpr (!BIG) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) accb[i][j] = 0.f;
+    }
+    auto mround = [&]() {
+        if constexpr (!BIG) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                if constexpr (AGPR) mfma16a(acc[i], fa[i & 3], fb[(i >> 2) & 3]);
+                else mfma16(acc[i], fa[i & 3], fb[(i >> 2) & 3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) mfma32(accb[i], fa[i & 3], fb[(i >> 2) & 3]);
+        }
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int grp = wave >> 2;
+    unsigned long long t0 = 0, t1 = 0;
+    if (MODE >= 2 && grp == 1) bar();
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0) {
+            mround();
+        } else if constexpr (MODE == 1) {
+            mround();
+            bar();
+        } else {
+            // idle / R round
+            if constexpr (MODE >= 3) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const bf16x8 v = *(const __attribute__((address_space(3))) bf16x8*)(lds + ((r * 64 + lane) * 16 + (it & 3) * 8192));
+                    if (r < 4) fa[r] = v; else fb[r & 3] = v;
+                }
+            }
+            if constexpr (MODE >= 4) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((it * ND + d) * 64 + lane) % 4096),
+                                                     (__attribute__((address_space(3))) void*)(lds + 65536 + (wave * ND + d) * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+            }
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mround();
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+        }
+    }
+    t1 = __builtin_amdgcn_s_memtime();
+    if (MODE >= 2 && grp == 0) bar();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float s = 0.f;
+    if constexpr (!BIG) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += accb[i][j];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int MODE, int NM, int NR, int ND, bool BIG, bool AGPR>
+static void run(const char* name, int threads, int blocks, const bf16x8* src, float* out, unsigned long long* cyc) {
+    const int iters = 400;
+    hipFuncSetAttribute((const void*)probe<MODE, NM, NR, ND, BIG, AGPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((probe<MODE, NM, NR, ND, BIG, AGPR>), dim3(blocks), dim3(threads), 96 * 1024, 0, src, out, cyc, iters, threads);
+        hipDeviceSynchronize();
+    }
+    // wall clock of a long run (all blocks): TFLOP/s by hipEvents, to read next to the cycle counter
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int long_iters = 20000;
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((probe<MODE, NM, NR, ND, BIG, AGPR>), dim3(blocks), dim3(threads), 96 * 1024, 0, src, out, cyc, long_iters, threads);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> hl(blocks * 8);
+    hipMemcpy(hl.data(), cyc, hl.size() * 8, hipMemcpyDeviceToHost);
+    const double flops = (double)blocks * (threads / 64) * long_iters * NM * 16384.0;
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    const double ghz = (double)hl[0] / (ms * 1e-3) / 1e9;  // counter ticks per second over the long run
+    hipLaunchKernelGGL((probe<MODE, NM, NR, ND, BIG, AGPR>), dim3(blocks), dim3(threads), 96 * 1024, 0, src, out, cyc, iters, threads);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 8);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    const int waves = threads / 64;
+    // MFMA work per SIMD per round: waves/4 waves x NM MFMAs x 16 cycles; ping-pong modes run 2 rounds (G0's and G1's) per iteration
+    const double per_iter = (double)h[0] / iters;
+    const double ideal = MODE >= 2 ? 2.0 * NM * 16.0 : (double)(waves > 4 ? waves / 4 : 1) * NM * 16.0;
+    printf("%-52s blocks %3d  cyc/iter %8.1f  ideal %5.0f  util %5.1f %% | wall %7.1f TFLOP/s, counter %.2f GHz\n", name, blocks, per_iter, ideal,
+           100.0 * ideal / per_iter, tf, ghz);
+}
+
+int main() {
+    bf16x8* src;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&src, 4096 * 16);
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&cyc, 256 * 8 * 8);
+    std::vector<unsigned short> h(4096 * 8);
+    for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff)) ^ ((rand() & 1) << 15);  // bf16 values of magnitude ~1, random sign
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    for (int blocks : {1, 256}) {
+        run<0, 16, 0, 0, false, false>("free-running, 1 wave/SIMD, 16 x 16x16x32", 256, blocks, src, out, cyc);
+        run<0, 16, 0, 0, false, true>("free-running, 1 wave/SIMD, 16 x 16x16x32, AGPR acc", 256, blocks, src, out, cyc);
+        run<0, 16, 0, 0, true, false>("free-running, 1 wave/SIMD, 8 x 32x32x16", 256, blocks, src, out, cyc);
+        run<0, 16, 0, 0, false, false>("free-running, 2 waves/SIMD, 16 x 16x16x32 each", 512, blocks, src, out, cyc);
+        run<1, 16, 0, 0, false, false>("barrier per round, 2 waves/SIMD, 16 each", 512, blocks, src, out, cyc);
+        run<1, 48, 0, 0, false, false>("barrier per round, 2 waves/SIMD, 48 each", 512, blocks, src, out, cyc);
+        run<2, 8, 0, 0, false, false>("ping-pong, 8 MFMA per M round", 512, blocks, src, out, cyc);
+        run<2, 16, 0, 0, false, false>("ping-pong, 16 MFMA per M round", 512, blocks, src, out, cyc);
+        run<2, 32, 0, 0, false, false>("ping-pong, 32 MFMA per M round", 512, blocks, src, out, cyc);
+        run<2, 16, 0, 0, true, false>("ping-pong, 8 x 32x32x16 per M round", 512, blocks, src, out, cyc);
+        run<3, 16, 8, 0, false, false>("ping-pong, 16 MFMA, 8 ds_read_b128 in R", 512, blocks, src, out, cyc);
+        run<3, 32, 8, 0, false, false>("ping-pong, 32 MFMA, 8 ds_read_b128 in R", 512, blocks, src, out, cyc);
+        run<4, 16, 8, 2, false, false>("ping-pong, 16 MFMA, 8 ds_read + 2 LDS-DMA in R", 512, blocks, src, out, cyc);
+        run<4, 32, 8, 2, false, false>("ping-pong, 32 MFMA, 8 ds_read + 2 LDS-DMA in R", 512, blocks, src, out, cyc);
+        run<4, 32, 8, 4, false, false>("ping-pong, 32 MFMA, 8 ds_read + 4 LDS-DMA in R", 512, blocks, src, out, cyc);
+    }
+    return 0;
+}

@@ -37,6 +37,7 @@ struct IgFwdParams {
     int ncob;
     int lsw;              // log2(g.SW) for the aligned-tile kernels (igemm_fwd2)
     int dbg;              // developer A/B switch (RSU_FWD_DBG): bit 0 = skip weight staging, bit 1 = skip halo staging (timing only)
+    unsigned* stamps;     // diagnostic time stamps of igemm_pp (RSU_FWD_DBG bit 7 + RSU_STAMP_PTR), else null
     TileGeo g;
 };
 
@@ -52,6 +53,8 @@ IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg);
 int igemm_fwd2_max_pieces(int cfg, int ntap);
 size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max);
 hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
+// third generation (ping-pong wave groups; igemm_pp.hip): 3x3 taps, stride 1; tile shapes, LDS budget and results as igemm_fwd2
+hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 // ntap in {1,4,9}
 hipError_t igemm_fwd_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 

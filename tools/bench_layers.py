@@ -67,8 +67,12 @@ def main():
     ap.add_argument("--cfgs", default="-1")
     ap.add_argument("--ops", default="fwd,bwd,wg")
     ap.add_argument("--only", default="")
+    ap.add_argument("--gens", default="", help="comma list of RSU_FWD_GEN values to time side by side (fwd / bwd ops)")
+    ap.add_argument("--dbg", default="", help="comma list of RSU_FWD_DBG values to time side by side")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
+    gens = [g for g in args.gens.split(",") if g] or [None]
+    dbgs = [g for g in args.dbg.split(",") if g] or [None]
     ops = args.ops.split(",")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot = {}
@@ -97,7 +101,11 @@ def main():
         fl = 2.0 * B * ho * ho * cout * cin * 9
         line = "%-14s H%4d C%4d->%4d d%d %7.1f GF |" % (name, hin, cin, cout, dil, fl / 1e9)
         for op in ops:
-            for cfg in (cfgs if op != "wg" else [-1]):
+            for cfg, gen, dbg in [(c, g, d) for c in (cfgs if op != "wg" else [-1]) for g in (gens if op != "wg" else [None]) for d in (dbgs if op != "wg" else [None])]:
+                if gen is not None:
+                    os.environ["RSU_FWD_GEN"] = gen
+                if dbg is not None:
+                    os.environ["RSU_FWD_DBG"] = dbg
                 if cfg >= 0:
                     os.environ["RSU_FWD2_CFG"] = str(cfg)
                 else:
@@ -111,11 +119,14 @@ def main():
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, st))
                     else:
                         t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
-                    line += " %s%s %6.0fus %5.0fTF |" % (op, "" if cfg < 0 else "[%d]" % cfg, t * 1e6, fl / t / 1e12)
-                    tot[(op, cfg)] = tot.get((op, cfg), 0.0) + t
+                    tag = ("" if cfg < 0 else "[%d]" % cfg) + ("" if gen is None else "g" + gen) + ("" if dbg is None else "d" + dbg)
+                    line += " %s%s %6.0fus %5.0fTF |" % (op, tag, t * 1e6, fl / t / 1e12)
+                    tot[(op, tag)] = tot.get((op, tag), 0.0) + t
                 except Exception as ex:
                     line += " %s[%d] n/a |" % (op, cfg)
         os.environ.pop("RSU_FWD2_CFG", None)
+        os.environ.pop("RSU_FWD_GEN", None)
+        os.environ.pop("RSU_FWD_DBG", None)
         print(line, flush=True)
     print("totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()})
 
