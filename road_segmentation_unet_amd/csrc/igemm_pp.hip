@@ -1,25 +1,27 @@
-// igemm_pp: third generation of the NHWC bf16 implicit-GEMM 3x3 convolution (forward and backward-data): the persistent stage
-// stream of igemm_fwd2 (same data layout: fragment-ordered weights, pixel-major swizzled halo tile, channel-permuted 16-byte
-// stores, same tile shapes and the same summation order, so results are bit-identical) run as a PING-PONG between the two
-// waves of every SIMD.
+// igemm_pp: third generation of the NHWC bf16 implicit-GEMM 3x3 convolution (forward and backward-data): the data layout, tile
+// shapes and summation order of igemm_fwd2 (fragment-ordered weights, pixel-major swizzled halo tile, channel-permuted 16-byte
+// stores; results are bit-identical) run as a PING-PONG between the two waves of every SIMD.
 //
-// The eight waves of a workgroup form two groups, G0 = waves 0-3 and G1 = waves 4-7 (waves w and w+4 share a SIMD). Time is cut
-// into INTERVALS by workgroup barriers. A PHASE is one tap of one 32-channel chunk: CT+PT fragment reads and CT*PT MFMAs per
-// wave. Every wave runs   R(0) | M(0) | R(1) | M(1) | ...   with a barrier at every '|', where R(p) issues the LDS fragment
-// reads of phase p plus all the bookkeeping (LDS-DMA prefetches, counted waits, tile changes, the epilogue of the finished tile)
-// and M(p) is nothing but the phase's MFMAs. G1 starts one interval late, so in every interval one wave of each SIMD feeds the
-// matrix pipe while its partner does everything else: LDS latency, the issue cost of the LDS-DMA instructions (60-185 cycles
-// each, what bounded igemm_fwd2) and the address arithmetic no longer sit in a wave's own MFMA stream, and a wave needs only ONE
-// set of fragment registers (it never reads and multiplies at the same time).
+// What the measurements said (probes/probe_mfma_rate.hip, tools/pp_stamps.py): a SIMD's matrix pipe sustains 97-99 % of its
+// issue slots when ONE wave feeds it back to back while its partner does everything else, but a single wave issues only about
+// one instruction per 5 cycles -- LDS reads, scalar bookkeeping and LDS-DMA alike. igemm_fwd2 mixes all of that into every wave's
+// MFMA stream (37 % of the pipe). Here the eight waves form two groups, G0 = waves 0-3 and G1 = waves 4-7 (waves w and w+4 share
+// a SIMD), and time is cut into INTERVALS by workgroup barriers. A PHASE is one stage = the three taps of one kernel row of one
+// 32-channel chunk: 3*(CT+PT) fragment reads and 3*CT*PT MFMAs per wave. Every wave runs
+//        R(0) | M(0) | R(1) | M(1) | ...                  ('|' = barrier)
+// where R(s) holds the LDS fragment reads of stage s and ALL bookkeeping (LDS-DMA prefetch, counted waits, tile changes, the
+// epilogue of the finished tile) and M(s) is nothing but the stage's MFMAs (48 at the 64x64 wave tile: 768 pipe cycles, enough
+// to cover the ~70 instructions of an R interval). G1 starts one interval late, so in every interval one wave of each SIMD
+// multiplies while its partner reads and prefetches. A wave holds one stage of fragments and never reads while it multiplies.
 //
-// Ring discipline (stage = 3 taps of a chunk, weight ring of 3 stage slots = slot j for stage j of every chunk; halo ring of 2
-// chunk slots), in global intervals (G0 runs R(p) in interval 2p, G1 in 2p+1; a wave's reads of R(p) have landed at the latest
-// when its M(p) has issued its last MFMA):
-//   * the weights of stage s+2 go to the slot stage s-1 used: its last reader is G1's R(3s-1) in interval 6s-1, retired by the end
-//     of interval 6s, so the slot may be written from interval 6s+1 on: the waves issue in R(3s+1) (G0: 6s+2, G1: 6s+3);
-//   * the halo of chunk c+1 goes to the slot of chunk c-1, free from interval 18c+1 on: issued in R(9c+2) ... R(9c+6);
-//   * a wave waits for its own pieces of stage s+1 (and, in the chunk's last phase, of the next halo) with a COUNTED
-//     s_waitcnt vmcnt(N) at the end of R(3s+2): a barrier lies between that wait and the first read of the data (G0's R(3s+3)).
+// The two groups also split the prefetch streams: G1 owns the weights, G0 the halo tiles. In global intervals (G0 runs R(s) in
+// interval 2s, M(s) in 2s+1; G1 one later; a wave's reads of R(s) have landed when its M(s) has issued its last MFMA):
+//   * weights: ring of 3 stage slots, stage j of every chunk in slot j. In R(s) (interval 2s+1) a G1 wave issues its pieces of
+//     stage s+2 into the slot stage s-1 used (last read: G1's own R(s-1), interval 2s-1, retired in 2s), then waits with a
+//     counted vmcnt for its pieces of stage s+1 (issued in 2s-1); the barrier closing 2s+1 publishes them to G0's R(s+1) (2s+2).
+//   * halo: ring of 2 chunk slots. In R(3c+1) (interval 6c+2) a G0 wave issues its pieces of chunk c+1 into the slot chunk c-1
+//     used (last read: G1's R(3c-1), interval 6c-1, retired in 6c) and waits for them behind its MFMAs of M(3c+2) (interval 6c+5);
+//     the barrier closing 6c+5 publishes them to G0's R(3c+3) (6c+6).
 #include <type_traits>
 
 #include "igemm.h"
@@ -28,7 +30,6 @@
 #define RSU_SENT 0x80000000u   // voffset that the range check always rejects (num_records = 0x7fffffff)
 
 namespace {
-
 __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -38,34 +39,25 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
     h = __builtin_elementwise_max(h, s2{0, 0});
     return __builtin_bit_cast(unsigned, h);
 }
-
-// halo pieces of the next chunk are issued in the R intervals of phases 2, 3, 5 and 6 (never beside the weight pieces of
-// phases 1, 4, 7): slot i of {2,3,5,6} carries NA/4 pieces, the first NA%4 slots one more
-constexpr int a_slot_of(int pp) { return pp == 2 ? 0 : (pp == 3 ? 1 : (pp == 5 ? 2 : (pp == 6 ? 3 : -1))); }
-constexpr int a_cnt_slot(int NA, int i) { return NA / 4 + (i < NA % 4 ? 1 : 0); }
-constexpr int a_cnt(int NA, int pp) { return a_slot_of(pp) < 0 ? 0 : a_cnt_slot(NA, a_slot_of(pp)); }
-constexpr int a_first(int NA, int pp) {
-    int n = 0;
-    for (int i = 0; i < a_slot_of(pp); ++i) n += a_cnt_slot(NA, i);
-    return n;
-}
-
 }  // namespace
 
-// STAMP: diagnostic build (RSU_FWD_DBG bit 7 + RSU_STAMP_PTR): every wave notes s_memtime behind each barrier (in LDS, dumped to
-// p.stamps at the end: [block][wave][PP_NSTAMP]); tools/pp_stamps.py prints the interval lengths. Never on the product path.
+// STAMP: diagnostic build (RSU_FWD_DBG bit 7 + RSU_STAMP_PTR): every wave notes s_memtime in front of and behind each barrier
+// (in LDS, dumped to p.stamps at the end: [block][wave][PP_NSTAMP]); tools/pp_stamps.py prints the interval lengths. Never on the
+// product path.
 #define PP_NSTAMP 640
+// NA = halo DMA pieces per G0 wave per chunk (NA * 4 * 16 halo pixels at most)
 template <int WCO, int WPX, int CT, int PT, int NA, bool STAMP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 igemm_pp_kernel(const IgFwdParams p) {
-    constexpr int NW = 8, NTAP = 9, KW = 3, TPS = 3;
+    constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
     static_assert(WCO * WPX == NW, "eight waves: two per SIMD");
     constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
     constexpr int WT = TN / 16;
     constexpr int WBUF = TPS * WT * 1024;
-    constexpr int NWB = 3, NAB = 2, DW = 2;
-    constexpr int WPS = (TPS * WT + NW - 1) / NW;  // weight DMA instructions per wave per stage (padded to a constant)
-    constexpr int NST = (CT / 2) * PT;             // epilogue buffer stores per wave per tile (always issued)
+    constexpr int NWB = 3, NAB = 2;
+    static_assert((TPS * WT) % NG == 0, "weight pieces per stage split evenly over the four G1 waves");
+    constexpr int WPS = TPS * WT / NG;   // weight DMA instructions per G1 wave per stage
+    constexpr int NST = (CT / 2) * PT;   // epilogue buffer stores per wave per tile (always issued)
     static_assert((CT % 2) == 0, "bad config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
@@ -75,13 +67,14 @@ igemm_pp_kernel(const IgFwdParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
     const int wco = wave / WPX, wpx = wave % WPX;
     const int g4 = lane >> 4, l15 = lane & 15;
     const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TM >> lsw;
 
     // ---- this workgroup's tile list (XCD-aware numbering as in igemm_fwd2)
     int vid = blockIdx.x;
-    if (!(p.dbg & 64)) {
+    {
         const int q = gridDim.x >> 3, r = gridDim.x & 7, x = vid & 7;
         vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
     }
@@ -119,40 +112,41 @@ igemm_pp_kernel(const IgFwdParams p) {
             boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
         }
     }
+    const int afrag = (wco * CT * 64 + lane) * 16;  // this lane's 16 bytes inside weight tile 0 of the wave
+    const int row_bytes = (CW * p.dil) << 6;        // one kernel row down in the halo tile
     const int npieces = p.g.npix_max >> 4;
     const int lq = lane >> 2;
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
 
-    // ---- weight prefetch stream (one scalar source pointer that advances by a constant per stage and rewinds per tile)
+    // ---- weight prefetch stream (G1). Stage s of a tile is the contiguous block [s*3 .. s*3+3) x [all 16-row tiles] of the packed
+    // weights; a wave's WPS pieces have constant offsets inside it (folded into the per-lane voffset), the stage is one scalar
+    // offset that advances by a constant and rewinds per tile. The stream never ends: behind the last stage it simply starts the
+    // tile's weights again (valid memory, slots nobody reads), so the counted waits hold to the very end.
     const int nstage_tile = nchunks * 3;
-    const long stage_bytes = (long)TPS * p.ntiles_w * 1024;
-    const char* const w_tile_base = (const char*)p.wp + (long)(p.tile_off + cob * WT) * 1024;
-    const char* w_cur = w_tile_base;   // source of the next stage to prefetch
+    const unsigned stage_bytes = (unsigned)TPS * p.ntiles_w * 1024;
+    const unsigned w_tile_soff = (unsigned)(p.tile_off + cob * WT) * 1024u;
+    unsigned w_soff = w_tile_soff;     // stage to prefetch next
     int w_sit = 0;                     // its stage index inside the tile
-    int wpo[WPS];                      // byte offset of piece q inside a stage block, or -1 (padding piece / beyond the packed rows)
+    unsigned w_voff[WPS];              // per-lane byte offset of piece q inside a stage block
 #pragma unroll
     for (int q = 0; q < WPS; ++q) {
-        const int i = q * NW + wave;
+        const int i = q * NG + w4;
         const int tap_l = i / WT, tl = i - tap_l * WT;
-        const bool real = (i < TPS * WT) && (p.tile_off + cob * WT + tl < p.ntiles_w);
-        wpo[q] = real ? (tap_l * p.ntiles_w + tl) * 1024 : -1;
+        const bool real = p.tile_off + cob * WT + tl < p.ntiles_w;
+        w_voff[q] = real ? (unsigned)((tap_l * p.ntiles_w + tl) * 1024 + lane * 16) : RSU_SENT;
     }
     auto issue_w = [&](int slot) {
-        const int dst = slot * WBUF;
+        const __amdgpu_buffer_rsrc_t rw = mk(p.wp);
 #pragma unroll
-        for (int q = 0; q < WPS; ++q) {
-            const int i = q * NW + wave;
-            const char* base = wpo[q] >= 0 ? w_cur + wpo[q] : (const char*)p.zero_page;
-            dma16(base + lane * 16, (void*)(lds + (i < TPS * WT ? dst + i * 1024 : dummy_base)));
-        }
+        for (int q = 0; q < WPS; ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + slot * WBUF + (q * NG + w4) * 1024));
         if (++w_sit == nstage_tile) {
             w_sit = 0;
-            w_cur = w_tile_base;
+            w_soff = w_tile_soff;
         } else {
-            w_cur += stage_bytes;
+            w_soff += stage_bytes;
         }
     };
-    // ---- halo prefetch stream: exactly NA pieces per wave per chunk; clipped / padded pixels come back as zeros
+    // ---- halo prefetch stream (G0): exactly NA pieces per wave per chunk; clipped / padded pixels come back as zeros
     unsigned a_voff[NA];           // per-lane byte offset of piece q inside the current source, or RSU_SENT
     const char* a_ptr = nullptr;   // current source, shifted back by the padding so that every in-window offset is >= 0
     unsigned a_soff = 0;           // byte offset of the (padded) halo origin + channel chunk in that source
@@ -174,7 +168,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int iy0 = T.y0 - p.pad, ix0 = T.x0 - p.pad;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int hp = (q * NW + wave) * 16 + lq;
+            const int hp = (q * NG + w4) * 16 + lq;
             const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
             const int rr = div_magic(hp, p.g.inv_CW);
             const int cc = hp - rr * CW;
@@ -185,7 +179,7 @@ igemm_pp_kernel(const IgFwdParams p) {
     Tile ptile = decode(0);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
     bool a_started = false;
-    auto a_begin = [&]() {  // the next chunk of the stream moves on to the next source / tile where one ends
+    auto issue_a = [&]() {  // the next chunk of the stream (moves on to the next source / tile where one ends)
         if (a_cl == 0) {
             if (a_started) {
                 ++pk;
@@ -200,28 +194,23 @@ igemm_pp_kernel(const IgFwdParams p) {
             setup_a(ptile, a_si);
         }
         a_started = true;
-    };
-    auto a_pieces = [&](auto q0c, auto nc) {
-        constexpr int Q0 = decltype(q0c)::value, NQ = decltype(nc)::value;
         const __amdgpu_buffer_rsrc_t rs = mk(a_ptr);
         const int dst = a_base + ia_slot * ABUF;
         if (a_crem >= 32) {
 #pragma unroll
-            for (int q = Q0; q < Q0 + NQ; ++q) {
-                const int j = q * NW + wave;
+            for (int q = 0; q < NA; ++q) {
+                const int j = q * NG + w4;
                 bdma16(rs, a_voff[q], a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
             }
         } else {  // partial last chunk of a source whose channel count is not a multiple of 32: the missing channels read as zeros
 #pragma unroll
-            for (int q = Q0; q < Q0 + NQ; ++q) {
-                const int j = q * NW + wave;
+            for (int q = 0; q < NA; ++q) {
+                const int j = q * NG + w4;
                 const int hp = j * 16 + lq;
                 const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
                 bdma16(rs, kg8 < a_crem ? a_voff[q] : RSU_SENT, a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
             }
         }
-    };
-    auto a_end = [&]() {
         ia_slot ^= 1;
         a_soff += 64;
         a_crem -= 32;
@@ -234,7 +223,7 @@ igemm_pp_kernel(const IgFwdParams p) {
     int stamp_i = 0;
     auto stamp = [&]() {
         if constexpr (STAMP) {
-            if (stamp_i < PP_NSTAMP) {
+            if (stamp_i < PP_NSTAMP - 2) {
                 const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
                 if (lane == 0) *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + stamp_i) * 4) = t;
             }
@@ -261,6 +250,15 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
         return (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
     };
+// store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard); the diagnostic build
+// spills descriptor words, which come back through v_readlane right in front of the store: five more wait states there
+#define PP_STORE(R, VOFF)                                                                                                                       \
+    do {                                                                                                                                        \
+        if constexpr (STAMP)                                                                                                                    \
+            asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory"); \
+        else                                                                                                                                    \
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory");         \
+    } while (0)
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
@@ -281,10 +279,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                     r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
                     r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
                 }
-                if constexpr (STAMP)  // (the diagnostic build spills descriptor words: they come back through v_readlane right in front of the store)
-                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voff), "s"(orsrc), "s"(sbase) : "memory");
-                else
-                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voff), "s"(orsrc), "s"(sbase) : "memory");
+                PP_STORE(r, voff);
             }
             return;
         }
@@ -331,41 +326,40 @@ igemm_pp_kernel(const IgFwdParams p) {
                     r3 = relu_pk_bf16(r3);
                 }
                 const u32x4 r = {r0, r1, r2, r3};
-                // store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard)
-                if constexpr (STAMP)
-                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(orsrc), "s"(sbase)
-                                 : "memory");
-                else
-                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(orsrc), "s"(sbase)
-                                 : "memory");
+                PP_STORE(r, voffs[e]);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
         }
     };
-
-    // ---- prologue: W(0), A(0), W(1); everybody waits for its share of W(0) and A(0), one barrier publishes them
-    setup_a(ptile, 0);
-    a_next_src = p.nchunk[0];
-    issue_w(0);
-    a_begin();
-    a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
-    a_end();
-    if (GC * 3 > 1) {
-        issue_w(1);
-        RSU_WAIT_VMCNT(WPS);
-    } else {
-        RSU_WAIT_VMCNT(0);
-    }
-    // (raw barrier: __syncthreads() would drain the LDS-DMA stream; the bias words above are the only ordinary LDS stores)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (wave >= NW / 2) {  // G1 sits out interval 0
+    auto bar = [&]() {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-    }
+    };
 
+    // ---- prologue: G1 issues W(0), W(1) and waits for W(0); G0 issues A(0) and waits for it; one barrier publishes both
+    // (raw barrier: __syncthreads() would drain the LDS-DMA stream; the bias words above are the only ordinary LDS stores)
+    if (grp) {
+        if (!(p.dbg & 1)) {
+            issue_w(0);
+            issue_w(1);
+        }
+        RSU_WAIT_VMCNT(WPS);
+    } else {
+        setup_a(ptile, 0);
+        a_next_src = p.nchunk[0];
+        if (!(p.dbg & 2)) issue_a();
+        RSU_WAIT_VMCNT(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    if (grp) bar();  // G1 sits out interval 0
+
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (STAMP) {
+        clk0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     int gc = 0;       // stream chunk counter
     int ca_slot = 0;  // halo ring slot of the chunk being computed
     for (int ck = 0; ck < my_tiles; ++ck) {
@@ -383,107 +377,91 @@ igemm_pp_kernel(const IgFwdParams p) {
             }
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
-            const bool steady = gc + 1 < GC;          // the issues of this chunk's R intervals all take place
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
             const int ab = a_base + ca_slot * ABUF;
-            auto phase = [&](auto ppc) {
-                constexpr int PP = decltype(ppc)::value;
-                constexpr int J = PP / 3, TL = PP % 3;
-                const int st = gc * 3 + J;
-                // ================= R interval: fragment reads of this phase + bookkeeping for the phases ahead
-                bf16x8 fa[CT], fb[PT];
-                {
-                    constexpr int ky = PP / KW, kx = PP - ky * KW;
-                    const int rowoff = ab + ((ky * CW * p.dil) << 6);  // wave-uniform
+            auto phase = [&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                // ================= R interval: the stage's fragment reads + bookkeeping for the stages ahead
+                bf16x8 fa[TPS][CT], fb[TPS][PT];
+                if (!(p.dbg & 32)) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
+                    const int rowoff = ab + J * row_bytes;  // wave-uniform
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        fa[ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + J * WBUF + ((TL * WT + wco * CT + ct) * 64 + lane) * 16);
+                    for (int tl = 0; tl < TPS; ++tl) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            fa[tl][ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + afrag + J * WBUF + (tl * WT + ct) * 1024);
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][tl] + rowoff));
+                    }
+                }
+                if (grp) {
+                    if (!(p.dbg & 1)) issue_w((J + 2) % NWB);
+                    // this wave's pieces of the next stage (issued one phase ago) are the oldest loads still allowed in flight
+                    if (J == 0 && after_epi) {
+                        RSU_WAIT_VMCNT(WPS + NST);
+                    } else {
+                        RSU_WAIT_VMCNT(WPS);
+                    }
+                } else if (J == 1) {
+                    if (gc + 1 < GC && !(p.dbg & 2)) issue_a();
+                }
+                stamp();
+                bar();
+                stamp();
+                // ================= M interval: the MFMAs of this stage, nothing else
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if (!(p.dbg & 32))
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
-                        fb[pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][kx] + rowoff));
-                }
-                if constexpr (TL == 1) {
-                    if (st + DW < GC * 3 && !(p.dbg & 1)) issue_w((J + DW) % NWB);
-                }
-                if constexpr (a_cnt(NA, PP) > 0) {
-                    if (gc + 1 < GC && !(p.dbg & 2)) {
-                        if constexpr (a_first(NA, PP) == 0) a_begin();
-                        a_pieces(std::integral_constant<int, a_first(NA, PP)>{}, std::integral_constant<int, a_cnt(NA, PP)>{});
-                        if constexpr (a_first(NA, PP) + a_cnt(NA, PP) == NA) a_end();
-                    }
-                }
-                if constexpr (TL == 2) {
-                    // needed: the weights of the next stage (issued four phases ago) and, in the chunk's last phase, the next halo
-                    constexpr int ALLOWED = PP == 2 ? WPS + a_cnt(NA, 2)
-                                                    : (PP == 5 ? a_cnt(NA, 2) + a_cnt(NA, 3) + WPS + a_cnt(NA, 5) : WPS);
-                    if (!steady) {
-                        RSU_WAIT_VMCNT(0);
-                    } else if (PP == 2 && after_epi) {
-                        RSU_WAIT_VMCNT(ALLOWED + NST);
-                    } else {
-                        RSU_WAIT_VMCNT(ALLOWED);
-                    }
-                }
-                stamp();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                stamp();
-                // ================= M interval: the MFMAs of this phase, nothing else
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[ct], fb[pt]);
-                if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(0);
+                        for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[tl][ct], fb[tl][pt]);
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (PP == 8 && c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
+                if (J == 2) {
+                    if (!grp) RSU_WAIT_VMCNT(0);                  // G0: the next chunk's halo pieces (nothing younger is in flight)
+                    if (c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
+                }
                 stamp();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                bar();
                 stamp();
             };
             phase(std::integral_constant<int, 0>{});
             phase(std::integral_constant<int, 1>{});
             phase(std::integral_constant<int, 2>{});
-            phase(std::integral_constant<int, 3>{});
-            phase(std::integral_constant<int, 4>{});
-            phase(std::integral_constant<int, 5>{});
-            phase(std::integral_constant<int, 6>{});
-            phase(std::integral_constant<int, 7>{});
-            phase(std::integral_constant<int, 8>{});
             ca_slot ^= 1;
         }
         // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
         if (!(p.dbg & 8)) epilogue(ctile, acc);
     }
-    if (wave < NW / 2) {  // G0 sits out the last interval (G1's last epilogue)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    if (!grp) bar();  // G0 sits out the last interval (G1's last epilogue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in this workgroup's LDS after it has gone
     if constexpr (STAMP) {
         if (p.stamps) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned dclk = (unsigned)(__builtin_amdgcn_s_memtime() - clk0), drt = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
             for (int i = lane; i < PP_NSTAMP; i += 64)
                 p.stamps[((long)blockIdx.x * NW + wave) * PP_NSTAMP + i] =
-                    i < stamp_i ? *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + i) * 4) : 0u;
+                    i == PP_NSTAMP - 2 ? dclk : (i == PP_NSTAMP - 1 ? drt :  // shader cycles and 100-MHz ticks of the main loop
+                    (i < stamp_i ? *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + i) * 4) : 0u));
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int CFG> struct PpCfg;
-// NA = halo DMA pieces per wave per chunk (NA * 8 * 16 halo pixels at most), as in igemm_fwd2
-template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 4; };
-template <> struct PpCfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 6; };
-template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 3; };
-template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 4; };
-template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NA = 4; };
-template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NA = 5; };
-template <> struct PpCfg<IGF2_CFG_128x320> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 5, NA = 5; };
-template <> struct PpCfg<IGF2_CFG_64x640> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 5, NA = 7; };
+// NA = halo DMA pieces per G0 wave per chunk: igemm_fwd2's per-wave counts, doubled (four waves carry the halo stream here)
+template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 8; };
+template <> struct PpCfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 12; };
+template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 6; };
+template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 8; };
+template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NA = 8; };
+template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NA = 10; };
+template <> struct PpCfg<IGF2_CFG_128x320> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 5, NA = 10; };
+template <> struct PpCfg<IGF2_CFG_64x640> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 5, NA = 14; };
 
 template <int CFG, bool STAMP = false>
 static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {

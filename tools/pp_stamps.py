@@ -57,6 +57,12 @@ for _ in range(3):
     run()
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64).reshape(256, 8, NST) & 0xFFFFFFFF
+clk = s[:, 0, NST - 2].astype(np.float64)
+rt = s[:, 0, NST - 1].astype(np.float64)
+ok = rt > 0
+print("in-kernel clock (shader cycles / 100-MHz ticks, per workgroup): median %.3f GHz, min %.3f, max %.3f; loop length median %.1f us"
+      % (np.median(clk[ok] / rt[ok]) * 0.1, (clk[ok] / rt[ok]).min() * 0.1, (clk[ok] / rt[ok]).max() * 0.1, np.median(rt[ok]) * 0.01))
+s[:, :, NST - 2:] = 0
 # stamps per phase of a wave: [end of R work] barrier [start of M] ... [end of M issue] barrier [start of next R]
 for blk in (0, 100):
     t = s[blk]
