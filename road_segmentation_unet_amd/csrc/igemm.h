@@ -55,6 +55,7 @@ size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max);
 hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 // third generation (ping-pong wave groups; igemm_pp.hip): 3x3 taps, stride 1; tile shapes, LDS budget and results as igemm_fwd2
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
+bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
 // ntap in {1,4,9}
 hipError_t igemm_fwd_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 

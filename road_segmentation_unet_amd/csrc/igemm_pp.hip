@@ -14,14 +14,18 @@
 // to cover the ~70 instructions of an R interval). G1 starts one interval late, so in every interval one wave of each SIMD
 // multiplies while its partner reads and prefetches. A wave holds one stage of fragments and never reads while it multiplies.
 //
-// The two groups also split the prefetch streams: G1 owns the weights, G0 the halo tiles. In global intervals (G0 runs R(s) in
-// interval 2s, M(s) in 2s+1; G1 one later; a wave's reads of R(s) have landed when its M(s) has issued its last MFMA):
-//   * weights: ring of 3 stage slots, stage j of every chunk in slot j. In R(s) (interval 2s+1) a G1 wave issues its pieces of
-//     stage s+2 into the slot stage s-1 used (last read: G1's own R(s-1), interval 2s-1, retired in 2s), then waits with a
-//     counted vmcnt for its pieces of stage s+1 (issued in 2s-1); the barrier closing 2s+1 publishes them to G0's R(s+1) (2s+2).
-//   * halo: ring of 2 chunk slots. In R(3c+1) (interval 6c+2) a G0 wave issues its pieces of chunk c+1 into the slot chunk c-1
-//     used (last read: G1's R(3c-1), interval 6c-1, retired in 6c) and waits for them behind its MFMAs of M(3c+2) (interval 6c+5);
-//     the barrier closing 6c+5 publishes them to G0's R(3c+3) (6c+6).
+// Both prefetch streams are spread evenly over the R intervals of BOTH groups: the LDS-DMA path of a CU moves ~29 bytes per clock
+// from L2, and a wave that issues into a full queue stalls (a G1 wave issuing a whole stage of weights spent its whole R
+// interval there, a G0 wave issuing a whole halo tile twice that). Every wave ends its R interval with s_waitcnt lgkmcnt(0):
+// its fragments have landed before the barrier, so the slots it read may be overwritten from the NEXT interval on.
+// In global intervals (G0 runs R(s) in interval 2s, M(s) in 2s+1; G1 one later):
+//   * weights: ring of 3 stage slots, stage j of every chunk in slot j. In R(s) every wave issues its share of stage s+2 into the
+//     slot of stage s-1 (last read in interval 2s-1). The pieces of stage s+1 (issued in R(s-1)) must be published by the barrier
+//     closing interval 2s+1: G1 waits for its share at the end of R(s), G0 behind its MFMAs of M(s) -- counted vmcnt, the issues
+//     of R(s) stay in flight.
+//   * halo: ring of 2 chunk slots; the slot of chunk c-1 is free from interval 6c on. The pieces of chunk c+1 are issued in G0's
+//     R(3c), R(3c+1), R(3c+2) and G1's R(3c), R(3c+1) (always in front of the interval's weight pieces) and are covered by the
+//     same counted waits in interval 6c+5.
 #include <type_traits>
 
 #include "igemm.h"
@@ -45,8 +49,26 @@ __device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
 // (in LDS, dumped to p.stamps at the end: [block][wave][PP_NSTAMP]); tools/pp_stamps.py prints the interval lengths. Never on the
 // product path.
 #define PP_NSTAMP 640
-// NA = halo DMA pieces per G0 wave per chunk (NA * 4 * 16 halo pixels at most)
-template <int WCO, int WPX, int CT, int PT, int NA, bool STAMP>
+// The halo DMA pieces of a chunk are dealt over five (group, stage) slots G0/0, G1/0, G0/1, G1/1, G0/2 (NAW: pieces per wave in
+// each slot; their sum * 4 * 16 = halo pixels at most); wave w4 of the slot's group issues piece (first(slot) + t) * 4 + w4.
+// WP0 = weight pieces of a stage issued by each G0 wave (the G1 waves issue the rest)
+namespace {
+// (NAW packs the five per-slot counts, 4 bits each, slot 0 in the lowest nibble)
+constexpr int pp_na_slot(int NAW, int k) { return (NAW >> (4 * k)) & 15; }
+constexpr int pp_na(int NAW, int g, int j) { return g == 0 ? pp_na_slot(NAW, 2 * j) : (j < 2 ? pp_na_slot(NAW, 2 * j + 1) : 0); }
+constexpr int pp_na_first(int NAW, int g, int j) {  // per-wave piece index of the slot's first piece
+    int n = 0;
+    for (int k = 0; k < (g == 0 ? 2 * j : 2 * j + 1); ++k) n += pp_na_slot(NAW, k);
+    return n;
+}
+constexpr int pp_na_total(int NAW, int g) { return pp_na(NAW, g, 0) + pp_na(NAW, g, 1) + pp_na(NAW, g, 2); }
+constexpr int pp_na_idx(int NAW, int g, int j) {  // index of the slot's first piece in the wave's own offset array
+    int n = 0;
+    for (int k = 0; k < j; ++k) n += pp_na(NAW, g, k);
+    return n;
+}
+}  // namespace
+template <int WCO, int WPX, int CT, int PT, int NAW, int WP0, bool STAMP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 igemm_pp_kernel(const IgFwdParams p) {
     constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
@@ -55,8 +77,11 @@ igemm_pp_kernel(const IgFwdParams p) {
     constexpr int WT = TN / 16;
     constexpr int WBUF = TPS * WT * 1024;
     constexpr int NWB = 3, NAB = 2;
-    static_assert((TPS * WT) % NG == 0, "weight pieces per stage split evenly over the four G1 waves");
-    constexpr int WPS = TPS * WT / NG;   // weight DMA instructions per G1 wave per stage
+    // weight pieces of a stage (3 * WT): waves of G0 issue WP0 each (pieces q*4 + w4), waves of G1 WP1 each (pieces (WP0 + q)*4 + w4)
+    constexpr int WP1 = TPS * WT / 4 - WP0;
+    constexpr int WPM = WP1 > WP0 ? WP1 : (WP0 > 0 ? WP0 : 1);
+    constexpr int NAV = pp_na_total(NAW, 0) > pp_na_total(NAW, 1) ? pp_na_total(NAW, 0) : pp_na_total(NAW, 1);
+    static_assert((WP0 + WP1) * 4 == TPS * WT && WP0 >= 0 && WP1 >= 1, "weight pieces per stage");
     constexpr int NST = (CT / 2) * PT;   // epilogue buffer stores per wave per tile (always issued)
     static_assert((CT % 2) == 0, "bad config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,18 +152,19 @@ igemm_pp_kernel(const IgFwdParams p) {
     const unsigned w_tile_soff = (unsigned)(p.tile_off + cob * WT) * 1024u;
     unsigned w_soff = w_tile_soff;     // stage to prefetch next
     int w_sit = 0;                     // its stage index inside the tile
-    unsigned w_voff[WPS];              // per-lane byte offset of piece q inside a stage block
+    unsigned w_voff[WPM];              // per-lane byte offset of this wave's piece q inside a stage block
 #pragma unroll
-    for (int q = 0; q < WPS; ++q) {
-        const int i = q * NG + w4;
+    for (int q = 0; q < WPM; ++q) {
+        const int i = ((grp ? WP0 : 0) + q) * NG + w4;
         const int tap_l = i / WT, tl = i - tap_l * WT;
-        const bool real = p.tile_off + cob * WT + tl < p.ntiles_w;
+        const bool real = (q < (grp ? WP1 : WP0)) && (p.tile_off + cob * WT + tl < p.ntiles_w);
         w_voff[q] = real ? (unsigned)((tap_l * p.ntiles_w + tl) * 1024 + lane * 16) : RSU_SENT;
     }
-    auto issue_w = [&](int slot) {
+    auto issue_w = [&](auto gc_, int slot) {
+        constexpr int G = decltype(gc_)::value;
         const __amdgpu_buffer_rsrc_t rw = mk(p.wp);
 #pragma unroll
-        for (int q = 0; q < WPS; ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + slot * WBUF + (q * NG + w4) * 1024));
+        for (int q = 0; q < (G ? WP1 : WP0); ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + slot * WBUF + (((G ? WP0 : 0) + q) * NG + w4) * 1024));
         if (++w_sit == nstage_tile) {
             w_sit = 0;
             w_soff = w_tile_soff;
@@ -146,8 +172,9 @@ igemm_pp_kernel(const IgFwdParams p) {
             w_soff += stage_bytes;
         }
     };
-    // ---- halo prefetch stream (G0): exactly NA pieces per wave per chunk; clipped / padded pixels come back as zeros
-    unsigned a_voff[NA];           // per-lane byte offset of piece q inside the current source, or RSU_SENT
+    // ---- halo prefetch stream: NAW * 4 pieces per chunk; clipped / padded pixels come back as zeros. Every wave keeps the stream
+    // state (scalars) and the per-lane offsets of ITS pieces.
+    unsigned a_voff[NAV > 0 ? NAV : 1];  // per-lane byte offset of this wave's piece inside the current source, or RSU_SENT
     const char* a_ptr = nullptr;   // current source, shifted back by the padding so that every in-window offset is >= 0
     unsigned a_soff = 0;           // byte offset of the (padded) halo origin + channel chunk in that source
     int a_crem = 0;                // channels left in the current source (>= 32 except in a partial last chunk)
@@ -155,6 +182,17 @@ igemm_pp_kernel(const IgFwdParams p) {
     int a_next_src = 0;            // chunk index at which the next source begins
     int a_si = 0;                  // current source
     int ia_slot = 0;               // ring slot of the next halo
+    auto my_piece = [&](int idx) {  // halo piece (per chunk) behind entry idx of this wave's offset array
+        int pw = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i0 = grp ? pp_na_idx(NAW, 1, j) : pp_na_idx(NAW, 0, j);
+            const int n = grp ? pp_na(NAW, 1, j) : pp_na(NAW, 0, j);
+            const int f = grp ? pp_na_first(NAW, 1, j) : pp_na_first(NAW, 0, j);
+            if (idx >= i0 && idx < i0 + n) pw = f + idx - i0;
+        }
+        return pw * NG + w4;
+    };
     auto setup_a = [&](const Tile& T, int si) {
         const bf16_t* sptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
         const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
@@ -167,19 +205,20 @@ igemm_pp_kernel(const IgFwdParams p) {
         a_crem = sC;
         const int iy0 = T.y0 - p.pad, ix0 = T.x0 - p.pad;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int hp = (q * NG + w4) * 16 + lq;
+        for (int q = 0; q < NAV; ++q) {
+            const int hp = my_piece(q) * 16 + lq;
             const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
             const int rr = div_magic(hp, p.g.inv_CW);
             const int cc = hp - rr * CW;
-            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win);
+            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win) &&
+                            (q < (grp ? pp_na_total(NAW, 1) : pp_na_total(NAW, 0)));
             a_voff[q] = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
         }
     };
     Tile ptile = decode(0);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
     bool a_started = false;
-    auto issue_a = [&]() {  // the next chunk of the stream (moves on to the next source / tile where one ends)
+    auto a_begin = [&]() {  // the next chunk of the stream: moves on to the next source / tile where one ends
         if (a_cl == 0) {
             if (a_started) {
                 ++pk;
@@ -194,23 +233,31 @@ igemm_pp_kernel(const IgFwdParams p) {
             setup_a(ptile, a_si);
         }
         a_started = true;
-        const __amdgpu_buffer_rsrc_t rs = mk(a_ptr);
-        const int dst = a_base + ia_slot * ABUF;
-        if (a_crem >= 32) {
+    };
+    auto a_pieces = [&](auto gc_, auto jc_) {  // this wave's pieces of slot (G, J)
+        constexpr int G = decltype(gc_)::value, J = decltype(jc_)::value;
+        constexpr int I0 = pp_na_idx(NAW, G, J), N = pp_na(NAW, G, J), F = pp_na_first(NAW, G, J);
+        if constexpr (N > 0) {
+            const __amdgpu_buffer_rsrc_t rs = mk(a_ptr);
+            const int dst = a_base + ia_slot * ABUF;
+            if (a_crem >= 32) {
 #pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int j = q * NG + w4;
-                bdma16(rs, a_voff[q], a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
-            }
-        } else {  // partial last chunk of a source whose channel count is not a multiple of 32: the missing channels read as zeros
+                for (int t = 0; t < N; ++t) {
+                    const int j = (F + t) * NG + w4;
+                    bdma16(rs, a_voff[I0 + t], a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+                }
+            } else {  // partial last chunk of a source whose channel count is not a multiple of 32: the missing channels read as zeros
 #pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int j = q * NG + w4;
-                const int hp = j * 16 + lq;
-                const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
-                bdma16(rs, kg8 < a_crem ? a_voff[q] : RSU_SENT, a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+                for (int t = 0; t < N; ++t) {
+                    const int j = (F + t) * NG + w4;
+                    const int hp = j * 16 + lq;
+                    const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
+                    bdma16(rs, kg8 < a_crem ? a_voff[I0 + t] : RSU_SENT, a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+                }
             }
         }
+    };
+    auto a_end = [&]() {
         ia_slot ^= 1;
         a_soff += 64;
         a_crem -= 32;
@@ -250,19 +297,46 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
         return (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
     };
-// store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard); the diagnostic build
-// spills descriptor words, which come back through v_readlane right in front of the store: five more wait states there
-#define PP_STORE(R, VOFF)                                                                                                                       \
-    do {                                                                                                                                        \
-        if constexpr (STAMP)                                                                                                                    \
-            asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory"); \
-        else                                                                                                                                    \
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory");         \
-    } while (0)
+// store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard). The leading s_nop 4:
+// under register pressure the compiler parks descriptor words in VGPR lanes and brings them back through v_readlane right in front
+// of the store -- a VALU write of an SGPR that a VMEM instruction reads needs five wait states, which hipcc does not add for asm
+#define PP_STORE(R, VOFF) \
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory")
+#define PP_STORE64(R, VOFF) \
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:64\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory")
+    // tiles that lie inside the output (all but the last row / strip of an image) store through per-lane offsets computed once
+    unsigned ovoff[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int ml = (wpx * PT + pt) * 16 + l15;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        ovoff[pt] = (unsigned)(((ty * p.oW + tx) * p.outC + 8 * g4) * 2);
+    }
+    const bool co_inside = cob * TN + TN <= p.Cout;
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
+        const bool inside = co_inside && (T.y0 + TR <= p.Ho) && (T.x0 + SW <= p.Wo);  // wave-uniform
+        if (!p.mask_src && !p.accumulate && inside) {
+            typedef __attribute__((ext_vector_type(2))) short s2;
+            const short fl = p.relu ? (short)0 : (short)-32768;
+            const s2 floor2 = {fl, fl};
+#pragma unroll
+            for (int e = 0; e < NST; ++e) {
+                const int pt = e / (CT / 2), pp = e % (CT / 2);
+                u32x4 r;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
+                    const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
+                    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                    r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                }
+                if (pp == 0) PP_STORE(r, ovoff[pt]); else PP_STORE64(r, ovoff[pt]);
+            }
+            return;
+        }
         if (!p.mask_src && !p.accumulate) {
             typedef __attribute__((ext_vector_type(2))) short s2;
             const short fl = p.relu ? (short)0 : (short)-32768;
@@ -283,15 +357,16 @@ igemm_pp_kernel(const IgFwdParams p) {
             }
             return;
         }
-        constexpr int EB = NST % 4 == 0 ? 4 : 2;
-        static_assert(NST % EB == 0, "epilogue batches");
+        // every mask / accumulate load of the tile is requested before the first is used: one memory latency per tile, in registers
+        // the stage fragments no longer need (with both a mask and an accumulate source: two batches)
+        constexpr int EB = NST;
 #pragma unroll
         for (int b0 = 0; b0 < NST; b0 += EB) {
             unsigned voffs[EB];
             u32x4 mk4[EB], ob4[EB];
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                voffs[e] = out_voff(T, b0 + e);
+                voffs[e] = inside ? ovoff[(b0 + e) / (CT / 2)] + ((b0 + e) % (CT / 2)) * 64 : out_voff(T, b0 + e);
                 if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
                 if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
             }
@@ -337,21 +412,33 @@ igemm_pp_kernel(const IgFwdParams p) {
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: G1 issues W(0), W(1) and waits for W(0); G0 issues A(0) and waits for it; one barrier publishes both
-    // (raw barrier: __syncthreads() would drain the LDS-DMA stream; the bias words above are the only ordinary LDS stores)
-    if (grp) {
-        if (!(p.dbg & 1)) {
-            issue_w(0);
-            issue_w(1);
+    // ---- prologue: every wave issues its share of the halo of chunk 0 and of the weights of stages 0 and 1 and waits for all of
+    // it; one barrier publishes the lot (raw barrier: __syncthreads() would drain the LDS-DMA stream on every later use; the bias
+    // words above are the only ordinary LDS stores)
+    setup_a(ptile, 0);
+    a_next_src = p.nchunk[0];
+    a_begin();
+    if (!(p.dbg & 2)) {
+        if (grp) {
+            a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        } else {
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         }
-        RSU_WAIT_VMCNT(WPS);
-    } else {
-        setup_a(ptile, 0);
-        a_next_src = p.nchunk[0];
-        if (!(p.dbg & 2)) issue_a();
-        RSU_WAIT_VMCNT(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    a_end();
+    if (!(p.dbg & 1)) {
+        if (grp) {
+            issue_w(std::integral_constant<int, 1>{}, 0);
+            issue_w(std::integral_constant<int, 1>{}, 1);
+        } else {
+            issue_w(std::integral_constant<int, 0>{}, 0);
+            issue_w(std::integral_constant<int, 0>{}, 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     bar();
     if (grp) bar();  // G1 sits out interval 0
 
@@ -378,6 +465,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         }
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
+            const bool steady = gc + 1 < GC;            // a next chunk exists: its halo is prefetched and the counted waits apply
             const int ab = a_base + ca_slot * ABUF;
             auto phase = [&](auto jc) {
                 constexpr int J = decltype(jc)::value;
@@ -395,17 +483,33 @@ igemm_pp_kernel(const IgFwdParams p) {
                             fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][tl] + rowoff));
                     }
                 }
+                // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
                 if (grp) {
-                    if (!(p.dbg & 1)) issue_w((J + 2) % NWB);
-                    // this wave's pieces of the next stage (issued one phase ago) are the oldest loads still allowed in flight
-                    if (J == 0 && after_epi) {
-                        RSU_WAIT_VMCNT(WPS + NST);
-                    } else {
-                        RSU_WAIT_VMCNT(WPS);
+                    if constexpr (pp_na(NAW, 1, J) > 0 || J == 0) {
+                        if (steady && !(p.dbg & 2)) {
+                            if constexpr (J == 0) a_begin();
+                            a_pieces(std::integral_constant<int, 1>{}, jc);
+                        }
                     }
-                } else if (J == 1) {
-                    if (gc + 1 < GC && !(p.dbg & 2)) issue_a();
+                    if constexpr (J == 2) { if (steady) a_end(); }
+                    if (!(p.dbg & 1)) issue_w(std::integral_constant<int, 1>{}, (J + 2) % NWB);
+                    // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
+                    if (!steady) {
+                        RSU_WAIT_VMCNT(0);
+                    } else if (J == 0 && after_epi) {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
+                    } else {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
+                    }
+                } else {
+                    if (steady && !(p.dbg & 2)) {
+                        if constexpr (J == 0) a_begin();
+                        a_pieces(std::integral_constant<int, 0>{}, jc);
+                    }
+                    if constexpr (J == 2) { if (steady) a_end(); }
+                    if (!(p.dbg & 1)) issue_w(std::integral_constant<int, 0>{}, (J + 2) % NWB);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
                 stamp();
                 bar();
                 stamp();
@@ -421,10 +525,18 @@ igemm_pp_kernel(const IgFwdParams p) {
                         for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[tl][ct], fb[tl][pt]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (J == 2) {
-                    if (!grp) RSU_WAIT_VMCNT(0);                  // G0: the next chunk's halo pieces (nothing younger is in flight)
-                    if (c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
+                if (!grp) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
+                    if (!steady) {
+                        RSU_WAIT_VMCNT(0);
+                    } else if (J == 0 && after_epi) {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
+                    } else if (J == 2) {
+                        RSU_WAIT_VMCNT(WP0);
+                    } else {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0);
+                    }
                 }
+                if (J == 2 && c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
                 stamp();
                 bar();
                 stamp();
@@ -453,21 +565,27 @@ igemm_pp_kernel(const IgFwdParams p) {
 
 // ---------------------------------------------------------------------------------------------
 template <int CFG> struct PpCfg;
-// NA = halo DMA pieces per G0 wave per chunk: igemm_fwd2's per-wave counts, doubled (four waves carry the halo stream here)
-template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NA = 8; };
-template <> struct PpCfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NA = 12; };
-template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NA = 6; };
-template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NA = 8; };
-template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NA = 8; };
-template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NA = 10; };
-template <> struct PpCfg<IGF2_CFG_128x320> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 5, NA = 10; };
-template <> struct PpCfg<IGF2_CFG_64x640> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 5, NA = 14; };
+#define PP_NAS(a, b, c, d, e) ((a) | ((b) << 4) | ((c) << 8) | ((d) << 12) | ((e) << 16))
+// NAS: halo pieces per wave in the slots G0/0, G1/0, G0/1, G1/1, G0/2 (sum * 4 = igemm_fwd2's halo pieces per chunk: the same LDS budget)
+template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NAS = PP_NAS(0, 4, 4, 2, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NAS = PP_NAS(0, 1, 2, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NAS = PP_NAS(0, 3, 3, 2, 2), WP0 = 0; };
+// (the five-fragment shapes 128x320 / 64x640 do not fit: three taps of fragments beside 80 accumulators spill; igemm_fwd2 runs them)
+// experimental distributions of the 128x256 shape (RSU_PP_VAR = 1..5, developer A/B)
+template <int V> struct PpVar;
+template <> struct PpVar<1> { static constexpr int NAS = PP_NAS(2, 2, 2, 1, 1), WP0 = 3; };
+template <> struct PpVar<2> { static constexpr int NAS = PP_NAS(0, 0, 4, 0, 4), WP0 = 0; };
+template <> struct PpVar<3> { static constexpr int NAS = PP_NAS(3, 0, 3, 0, 2), WP0 = 0; };
+template <> struct PpVar<4> { static constexpr int NAS = PP_NAS(0, 0, 4, 0, 4), WP0 = 2; };
+template <> struct PpVar<5> { static constexpr int NAS = PP_NAS(0, 0, 8, 0, 0), WP0 = 0; };
 
-template <int CFG, bool STAMP = false>
-static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
-    using C = PpCfg<CFG>;
-    auto kern = igemm_pp_kernel<C::WCO, C::WPX, C::CT, C::PT, C::NA, STAMP>;
-    const size_t lds = igemm_fwd2_lds_bytes(CFG, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
+template <int WCO, int WPX, int CT, int PT, int NAS, int WP0, bool STAMP>
+static hipError_t pp_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, NAS, WP0, STAMP>;
+    const size_t lds = igemm_fwd2_lds_bytes(cfg, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
     static size_t lds_set = 0;
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -477,12 +595,31 @@ static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(512), lds, st, p);
     return hipGetLastError();
 }
+template <int CFG, bool STAMP = false>
+static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
+    using C = PpCfg<CFG>;
+    return pp_launch_kernel<C::WCO, C::WPX, C::CT, C::PT, C::NAS, C::WP0, STAMP>(CFG, p, gx, st);
+}
+template <int V>
+static hipError_t pp_launch_var(const IgFwdParams& p, int gx, hipStream_t st) {
+    return pp_launch_kernel<2, 4, 4, 4, PpVar<V>::NAS, PpVar<V>::WP0, false>(IGF2_CFG_128x256, p, gx, st);
+}
+bool igemm_pp_has(int cfg) { return cfg != IGF2_CFG_128x320 && cfg != IGF2_CFG_64x640; }
 // 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
     if ((p.dbg & 128) && p.stamps) {  // diagnostic build with interval time stamps
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, true>(p, gx, st);
         if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, true>(p, gx, st);
+    }
+    if (cfg == IGF2_CFG_128x256 && (p.dbg >> 8)) {
+        switch (p.dbg >> 8) {
+            case 1: return pp_launch_var<1>(p, gx, st);
+            case 2: return pp_launch_var<2>(p, gx, st);
+            case 3: return pp_launch_var<3>(p, gx, st);
+            case 4: return pp_launch_var<4>(p, gx, st);
+            case 5: return pp_launch_var<5>(p, gx, st);
+        }
     }
     switch (cfg) {
         case IGF2_CFG_128x256: return pp_launch_one<IGF2_CFG_128x256>(p, gx, st);
@@ -491,8 +628,6 @@ hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st
         case IGF2_CFG_64x256: return pp_launch_one<IGF2_CFG_64x256>(p, gx, st);
         case IGF2_CFG_128x192: return pp_launch_one<IGF2_CFG_128x192>(p, gx, st);
         case IGF2_CFG_64x384: return pp_launch_one<IGF2_CFG_64x384>(p, gx, st);
-        case IGF2_CFG_128x320: return pp_launch_one<IGF2_CFG_128x320>(p, gx, st);
-        case IGF2_CFG_64x640: return pp_launch_one<IGF2_CFG_64x640>(p, gx, st);
     }
     return hipErrorInvalidValue;
 }

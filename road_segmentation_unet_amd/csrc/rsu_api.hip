@@ -390,7 +390,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 // persistent conv launch of the chosen generation: the ping-pong kernel (igemm_pp.hip) runs the 3x3 stride-1 launches unless
 // RSU_FWD_GEN=2 asks for igemm_fwd2 (same tile shapes, same bits)
 static hipError_t launch_persistent(bool pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
-    if (pp) return igemm_pp_launch(cfg, p, gx, st);
+    if (pp && igemm_pp_has(cfg)) return igemm_pp_launch(cfg, p, gx, st);
     return igemm_fwd2_launch(cfg, ntap, p, gx, gy, st);
 }
 
@@ -401,7 +401,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     const long out_bytes = (long)N * oH * oW * outC * 2;
     const int gen = env_int("RSU_FWD_GEN", 3);
     bool gen2 = gen >= 2 && out_bytes < 0x7ffffff0L;
-    const bool pp = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1;
+    // RSU_FWD_GEN: 2 = igemm_fwd2 only; 3 (default) = the ping-pong kernel where it measured (or, untuned, is expected to be) faster;
+    // 4 = the ping-pong kernel wherever it is built (tests)
+    const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1;
     for (int i = 0; i < nsrc; ++i)
         if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) gen2 = false;
     FwdPlan pl;
@@ -414,12 +416,17 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     const bool tunable = gen2 && env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc, (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0),
                                 ostride, g_cu_budget.load() * 4 + gen};
-    int tuned_cfg = -1;
+    int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
     bool tune_now = false;
     if (tunable) {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = g_tuned.find(tkey);
-        if (it != g_tuned.end()) tuned_cfg = it->second; else tune_now = true;
+        if (it != g_tuned.end()) {
+            tuned_cfg = it->second & 255;
+            tuned_pp = it->second >> 8;
+        } else {
+            tune_now = true;
+        }
     }
     bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip);
     if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
@@ -452,6 +459,10 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
     if (use2) {
+        // untuned choice of the kernel generation: the ping-pong kernel on the 128-channel shapes (measured +5-10 % there; the
+        // 64-channel shapes keep more halo offsets per wave than their registers hold)
+        const bool pp = pp_ok && igemm_pp_has(pl2.cfg) &&
+                        (gen >= 4 || (tuned_pp >= 0 ? tuned_pp != 0 : igemm_fwd2_cfg_info(pl2.cfg).TN >= 128));
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
@@ -474,12 +485,20 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             // time every admissible shape of the same channel-block width (1 untimed + 5 timed launches each, fastest counts, device idle; the
             // launches all write the same values, so the output is valid whichever ran last)
             const int tn_model = igemm_fwd2_cfg_info(pl2.cfg).TN;
-            hipEvent_t e0, e1;
-            HIP_CHECK_RET(hipEventCreate(&e0));
-            HIP_CHECK_RET(hipEventCreate(&e1));
+            struct EventPair {  // destroyed on every exit path
+                hipEvent_t a = nullptr, b = nullptr;
+                ~EventPair() {
+                    if (a) (void)hipEventDestroy(a);
+                    if (b) (void)hipEventDestroy(b);
+                }
+            } ev;
+            HIP_CHECK_RET(hipEventCreate(&ev.a));
+            HIP_CHECK_RET(hipEventCreate(&ev.b));
+            const hipEvent_t e0 = ev.a, e1 = ev.b;
             HIP_CHECK_RET(hipDeviceSynchronize());
             float best_ms = 1e30f, model_ms = 1e30f;
-            int best_cfg = pl2.cfg;
+            int best_cfg = pl2.cfg | ((pp ? 1 : 0) << 8);
+            const int model_code = best_cfg;
             for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
                 if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
                 Fwd2Plan pc;
@@ -488,29 +507,32 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                 pt.ncob = pc.ncob;
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
-                float ms_min = 1e30f;
-                for (int rep = 0; rep < 6; ++rep) {
-                    HIP_CHECK_RET(hipEventRecord(e0, st));
-                    HIP_CHECK_RET(launch_persistent(pp, pc.cfg, ntap, pt, pc.grid_x, gy, st));
-                    HIP_CHECK_RET(hipEventRecord(e1, st));
-                    HIP_CHECK_RET(hipEventSynchronize(e1));
-                    float ms = 0.f;
-                    HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
-                    if (rep > 0 && ms < ms_min) ms_min = ms;
-                }
-                if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] cfg%d %.1f us\n", cfg, ms_min * 1e3f);
-                if (cfg == pl2.cfg) model_ms = ms_min;
-                if (ms_min < best_ms) {
-                    best_ms = ms_min;
-                    best_cfg = cfg;
+                for (int vpp = 0; vpp < 2; ++vpp) {  // both kernel generations of the shape
+                    if (vpp && !(pp_ok && igemm_pp_has(cfg))) continue;
+                    if (!vpp && gen >= 4 && pp_ok && igemm_pp_has(cfg)) continue;
+                    float ms_min = 1e30f;
+                    for (int rep = 0; rep < 6; ++rep) {
+                        HIP_CHECK_RET(hipEventRecord(e0, st));
+                        HIP_CHECK_RET(launch_persistent(vpp != 0, pc.cfg, ntap, pt, pc.grid_x, gy, st));
+                        HIP_CHECK_RET(hipEventRecord(e1, st));
+                        HIP_CHECK_RET(hipEventSynchronize(e1));
+                        float ms = 0.f;
+                        HIP_CHECK_RET(hipEventElapsedTime(&ms, e0, e1));
+                        if (rep > 0 && ms < ms_min) ms_min = ms;
+                    }
+                    if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] cfg%d pp%d %.1f us\n", cfg, vpp, ms_min * 1e3f);
+                    const int code = cfg | (vpp << 8);
+                    if (code == model_code) model_ms = ms_min;
+                    if (ms_min < best_ms) {
+                        best_ms = ms_min;
+                        best_cfg = code;
+                    }
                 }
             }
             // hysteresis: a shape replaces the cost model's choice only when it measured at least 3 % faster (one noisy sample must
             // not pin a slow shape for the rest of the run)
-            if (best_ms > 0.97f * model_ms) best_cfg = pl2.cfg;
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] model cfg%d -> measured cfg%d\n", pl2.cfg, best_cfg);
+            if (best_ms > 0.97f * model_ms) best_cfg = model_code;
+            if (env_int("RSU_PLAN_DEBUG", 0)) fprintf(stderr, "[tune fwd2] model cfg%d pp%d -> measured cfg%d pp%d\n", pl2.cfg, (int)pp, best_cfg & 255, best_cfg >> 8);
             std::lock_guard<std::mutex> lk(g_tune_mutex);
             g_tuned[tkey] = best_cfg;
             return RSU_OK;

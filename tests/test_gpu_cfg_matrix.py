@@ -16,15 +16,18 @@ from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
 from tests import hiputil as hu  # noqa: E402
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7])
+# (shape, RSU_FWD_GEN): 2 = igemm_fwd2, 4 = the ping-pong kernel igemm_pp wherever it is built (shapes 0-5; 6 and 7 fall back to igemm_fwd2)
+@pytest.fixture(params=[(c, g) for c in range(8) for g in (2, 4) if not (g == 4 and c >= 6)], ids=lambda cg: "cfg%d-gen%d" % cg)
 def forced_cfg(request):
-    old = os.environ.get("RSU_FWD2_CFG")
-    os.environ["RSU_FWD2_CFG"] = str(request.param)
-    yield request.param
-    if old is None:
-        os.environ.pop("RSU_FWD2_CFG", None)
-    else:
-        os.environ["RSU_FWD2_CFG"] = old
+    old = {k: os.environ.get(k) for k in ("RSU_FWD2_CFG", "RSU_FWD_GEN")}
+    os.environ["RSU_FWD2_CFG"] = str(request.param[0])
+    os.environ["RSU_FWD_GEN"] = str(request.param[1])
+    yield request.param[0]
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _rand(rng, *shape, scale=1.0):
@@ -139,3 +142,35 @@ def test_conv3x3_bwd_weight_both_shapes(wg_cfg, N, H, W, Cin, Cout, dil):
             os.environ.pop("RSU_WG_CFG", None)
         else:
             os.environ["RSU_WG_CFG"] = old
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_pingpong_kernel_gives_the_bits_of_igemm_fwd2(cfg):
+    """igemm_pp keeps igemm_fwd2's summation order: forward and masked backward-data agree bit for bit, shape by shape."""
+    rng = np.random.RandomState(7 + cfg)
+    N, H, W, Cin, Cout = 2, 90, 84, 96, 128
+    x = hu.q(_rand(rng, N, H, W, Cin))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    dz = hu.q(_rand(rng, N, H - 2, W - 2, Cout, scale=0.1))
+    xd, wp, bd, dzd, wb = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b), hu.dev_bf16(dz), hu.pack_conv_bwd(w, 0, Cin)
+    s = (RsuSrc * 1)(hu.src_of(xd, H, W))
+    old = {k: os.environ.get(k) for k in ("RSU_FWD2_CFG", "RSU_FWD_GEN")}
+    out = {}
+    try:
+        os.environ["RSU_FWD2_CFG"] = str(cfg)
+        for gen in (2, 4):
+            os.environ["RSU_FWD_GEN"] = str(gen)
+            y = torch.full((N, H - 2, W - 2, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+            dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+            call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, 1, 1, hu.stream())
+            call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), hu.ptr(xd), 0, N, H, W, Cin, 0, Cin, Cout, 1, hu.stream())
+            out[gen] = (y.view(torch.int16).cpu().numpy().copy(), dx.view(torch.int16).cpu().numpy().copy())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert np.array_equal(out[2][0], out[4][0]), "forward differs between igemm_fwd2 and igemm_pp (shape %d)" % cfg
+    assert np.array_equal(out[2][1], out[4][1]), "backward-data differs between igemm_fwd2 and igemm_pp (shape %d)" % cfg
