@@ -248,25 +248,45 @@ igemm_fwd2_kernel(const IgFwdParams p) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
-        if (!p.mask_src && !p.accumulate) {
-            // the common case (forward, backward-data without a ReLU mask) without a single branch per store: ReLU as a packed int16
-            // max against 0 or, switched off, against the most negative int16 (bf16 sign bit == int16 sign bit)
+        if (!p.accumulate) {
+            // forward and backward-data without an AddN, without a single branch per store: everything on the packed bf16 result.
+            // ReLU is a packed int16 max against 0 or, switched off, against the most negative int16 (bf16 sign bit == int16 sign
+            // bit); the ReLU mask of backward-data (relu_src > 0) is a packed 0 / 0xffff word ANDed onto it: max(x, 0) -> min(., 1)
+            // -> 0 - . (a positive NaN in relu_src counts as > 0 here; no finite activation is affected). The mask loads go out in
+            // batches of four (one memory latency per batch)
             typedef __attribute__((ext_vector_type(2))) short s2;
             const short fl = p.relu ? (short)0 : (short)-32768;
             const s2 floor2 = {fl, fl};
+            unsigned ones_pk = 0x00010001u;
+            asm volatile("" : "+v"(ones_pk));
+            constexpr int MB = NST % 4 == 0 ? 4 : 2;
 #pragma unroll
-            for (int e = 0; e < NST; ++e) {
-                const int pt = e / (CT / 2), pp = e % (CT / 2);
-                const unsigned voff = out_voff(T, e);
-                u32x4 r;
+            for (int b0 = 0; b0 < NST; b0 += MB) {
+                unsigned voffs[MB];
+                u32x4 mk4[MB];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
-                    const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
-                    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
-                    r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                for (int e = 0; e < MB; ++e) {
+                    voffs[e] = out_voff(T, b0 + e);
+                    if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
                 }
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voff), "s"(orsrc), "s"(sbase) : "memory");
+#pragma unroll
+                for (int e = 0; e < MB; ++e) {
+                    const int pt = (b0 + e) / (CT / 2), pp = (b0 + e) % (CT / 2);
+                    u32x4 r;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
+                        const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
+                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                        r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                    }
+                    if (p.mask_src) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
+                    }
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(orsrc), "s"(sbase) : "memory");
+                }
+                if (p.mask_src) __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
             }
             return;
         }

@@ -318,33 +318,29 @@ igemm_pp_kernel(const IgFwdParams p) {
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
         const bool inside = co_inside && (T.y0 + TR <= p.Ho) && (T.x0 + SW <= p.Wo);  // wave-uniform
-        if (!p.mask_src && !p.accumulate && inside) {
+        if (!p.accumulate) {
+            // forward and backward-data without an AddN: everything on the packed bf16 result. ReLU is a packed int16 max against 0
+            // (or, switched off, against the most negative int16: bf16 sign bit == int16 sign bit); the ReLU mask of backward-data
+            // (relu_src > 0) is a packed 0 / 0xffff word ANDed onto it: max(x, 0) -> min(., 1) -> 0 - . (a positive NaN in relu_src
+            // counts as > 0 here; TensorFlow's ReluGrad lets nothing through there -- no finite activation is affected)
             typedef __attribute__((ext_vector_type(2))) short s2;
             const short fl = p.relu ? (short)0 : (short)-32768;
             const s2 floor2 = {fl, fl};
+            unsigned ones_pk = 0x00010001u;
+            asm volatile("" : "+v"(ones_pk));
+            u32x4 mk4[NST];
+            unsigned voffs[NST];
+            if (p.mask_src || !inside) {
 #pragma unroll
-            for (int e = 0; e < NST; ++e) {
-                const int pt = e / (CT / 2), pp = e % (CT / 2);
-                u32x4 r;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
-                    const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
-                    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
-                    r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
-                }
-                if (pp == 0) PP_STORE(r, ovoff[pt]); else PP_STORE64(r, ovoff[pt]);
+                for (int e = 0; e < NST; ++e) voffs[e] = inside ? ovoff[e / (CT / 2)] + (e % (CT / 2)) * 64 : out_voff(T, e);
             }
-            return;
-        }
-        if (!p.mask_src && !p.accumulate) {
-            typedef __attribute__((ext_vector_type(2))) short s2;
-            const short fl = p.relu ? (short)0 : (short)-32768;
-            const s2 floor2 = {fl, fl};
+            if (p.mask_src) {  // every mask load of the tile is in flight before the first is used (the stage fragments are dead by now)
+#pragma unroll
+                for (int e = 0; e < NST; ++e) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
+            }
 #pragma unroll
             for (int e = 0; e < NST; ++e) {
                 const int pt = e / (CT / 2), pp = e % (CT / 2);
-                const unsigned voff = out_voff(T, e);
                 u32x4 r;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -353,7 +349,15 @@ igemm_pp_kernel(const IgFwdParams p) {
                     r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
                     r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
                 }
-                PP_STORE(r, voff);
+                if (p.mask_src) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
+                }
+                if (p.mask_src || !inside) {
+                    PP_STORE(r, voffs[e]);
+                } else {
+                    if (pp == 0) PP_STORE(r, ovoff[pt]); else PP_STORE64(r, ovoff[pt]);
+                }
             }
             return;
         }

@@ -29,6 +29,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, r);
 }
 
+// ---- packed ReLU mask: 0xffff in each half of the result where the bf16 half of m is > 0 (sign clear, not zero), else 0:
+// max(m, 0) -> min(., 1) -> 0 - . on packed int16 (bf16 sign bit == int16 sign bit). Three VALU instructions per two elements; as
+// plain vector code hipcc turns the same arithmetic into two compares, two selects and a permute. A positive NaN counts as > 0.
+__device__ __forceinline__ unsigned pos_mask_pk_bf16(unsigned m, unsigned ones_pk /* 0x00010001 in a VGPR */) {
+    unsigned t;
+    asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_i16 %0, %0, %2\n\tv_pk_sub_i16 %0, 0, %0" : "=&v"(t) : "v"(m), "v"(ones_pk));
+    return t;
+}
+
 // ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand): no register is freed by
 // an MFMA, so the compiler cannot rename an accumulator and re-use its old registers while the matrix pipe still reads them.
 // The asm is opaque to hipcc's hazard recogniser, so the CALLER owns the wait states around it (DESIGN.md section 4;
