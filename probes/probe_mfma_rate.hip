@@ -5,6 +5,9 @@
 //   mode 0: free-running, no barrier           mode 1: one s_barrier per round, all waves multiply together
 //   mode 2: ping-pong: groups G0 = waves 0-3, G1 = waves 4-7 alternate M rounds and idle rounds (two barriers per round)
 //   mode 3: ping-pong with NR ds_read_b128 in the idle round         mode 4: as 3 plus ND LDS-DMA pieces in the idle round
+//   mode 6: a phase shaped like igemm_pp's: 24 live ds_read_b128 (3 taps x (4 A + 4 B) fragments), 48 MFMAs, ND LDS-DMA pieces (L2-hot
+//           source) and 30 vector + 40 scalar instructions in the R round
+//   mode 5: as 3 plus ND vector (v_add) and 2*ND scalar instructions in the idle round (the address arithmetic of a real kernel)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -40,18 +43,37 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((__attribute__((address_space(3))) bf16x8*)lds)[i & 4095] = src[i & 4095];
     __syncthreads();
     constexpr int NACC = BIG ? NM / 2 : NM;
-    f32x4 acc[BIG ? 1 : NM];
+    f32x4 acc[BIG ? 1 : (MODE == 6 ? 16 : NM)];
     f32x16 accb[BIG ? NM / 2 : 1];
     if constexpr (!BIG) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (MODE == 6 ? 16 : NM); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
 #pragma unroll
             for (int j = 0; j < 16; ++j) accb[i][j] = 0.f;
     }
+    bf16x8 ka[3][4], kb[3][4];
+    if constexpr (MODE == 6) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ka[t][i] = fa[i];
+                kb[t][i] = fb[i];
+            }
+    }
     auto mround = [&]() {
+        if constexpr (MODE == 6) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) mfma16(acc[ct * 4 + pt], ka[t][ct], kb[t][pt]);
+            return;
+        }
         if constexpr (!BIG) {
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
@@ -87,7 +109,36 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
                     if (r < 4) fa[r] = v; else fb[r & 3] = v;
                 }
             }
-            if constexpr (MODE >= 4) {
+            if constexpr (MODE == 6) {
+                const int base = (it & 1) * 32768;
+#pragma unroll
+                for (int t = 0; t < NR / 8; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ka[t][i] = *(const __attribute__((address_space(3))) bf16x8*)(lds + base + ((t * 4 + i) * 64 + lane) * 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) kb[t][i] = *(const __attribute__((address_space(3))) bf16x8*)(lds + base + 12288 + ((t * 4 + i) * 64 + lane) * 16);
+                }
+                int vv = lane + it;
+                int sc = __builtin_amdgcn_readfirstlane(it);
+#pragma unroll
+                for (int d = 0; d < (AGPR ? 0 : 10); ++d)
+                    asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5" : "+v"(vv), "+s"(sc));
+                asm volatile("" ::"v"(vv), "s"(sc));
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((it * ND + d) * 64 + lane) % 4096),
+                                                     (__attribute__((address_space(3))) void*)(lds + 65536 + (wave * 8 + d) * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (MODE == 5) {
+                int vv = lane + it;
+                int sc = __builtin_amdgcn_readfirstlane(it);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) asm volatile("v_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5" : "+v"(vv), "+s"(sc));
+                asm volatile("" ::"v"(vv), "s"(sc));
+            }
+            if constexpr (MODE == 4) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((it * ND + d) * 64 + lane) % 4096),
@@ -107,7 +158,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
     float s = 0.f;
     if constexpr (!BIG) {
 #pragma unroll
-        for (int i = 0; i < NM; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        for (int i = 0; i < (MODE == 6 ? 16 : NM); ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     } else {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
@@ -177,6 +228,19 @@ int main() {
         run<2, 16, 0, 0, true, false>("ping-pong, 8 x 32x32x16 per M round", 512, blocks, src, out, cyc);
         run<3, 16, 8, 0, false, false>("ping-pong, 16 MFMA, 8 ds_read_b128 in R", 512, blocks, src, out, cyc);
         run<3, 32, 8, 0, false, false>("ping-pong, 32 MFMA, 8 ds_read_b128 in R", 512, blocks, src, out, cyc);
+        run<3, 48, 8, 0, false, false>("ping-pong, 48 MFMA, 8 ds_read_b128 in R", 512, blocks, src, out, cyc);
+        run<5, 48, 8, 12, false, false>("ping-pong, 48 MFMA, 8 ds_read + 12 VALU + 24 SALU in R", 512, blocks, src, out, cyc);
+        run<5, 48, 8, 40, false, false>("ping-pong, 48 MFMA, 8 ds_read + 40 VALU + 80 SALU in R", 512, blocks, src, out, cyc);
+        run<5, 48, 8, 100, false, false>("ping-pong, 48 MFMA, 8 ds_read + 100 VALU + 200 SALU in R", 512, blocks, src, out, cyc);
+        run<6, 48, 24, 0, false, false>("kernel-like phase: 48 MFMA | 24 ds_read + 30 VALU + 40 SALU", 512, blocks, src, out, cyc);
+        run<6, 48, 24, 0, false, true>("kernel-like phase: 48 MFMA | 24 ds_read, no ALU", 512, blocks, src, out, cyc);
+        run<6, 48, 16, 0, false, true>("kernel-like phase: 48 MFMA | 16 ds_read, no ALU", 512, blocks, src, out, cyc);
+        run<6, 48, 8, 0, false, true>("kernel-like phase: 48 MFMA | 8 ds_read, no ALU", 512, blocks, src, out, cyc);
+        run<6, 48, 8, 0, false, false>("kernel-like phase: 48 MFMA | 8 ds_read + 30 VALU + 40 SALU", 512, blocks, src, out, cyc);
+        run<6, 48, 0, 0, false, false>("kernel-like phase: 48 MFMA | 0 ds_read + 30 VALU + 40 SALU", 512, blocks, src, out, cyc);
+        run<6, 48, 0, 6, false, true>("kernel-like phase: 48 MFMA | 6 LDS-DMA only", 512, blocks, src, out, cyc);
+        run<6, 48, 24, 3, false, false>("kernel-like phase + 3 LDS-DMA pieces per wave", 512, blocks, src, out, cyc);
+        run<6, 48, 24, 6, false, false>("kernel-like phase + 6 LDS-DMA pieces per wave", 512, blocks, src, out, cyc);
         run<4, 16, 8, 2, false, false>("ping-pong, 16 MFMA, 8 ds_read + 2 LDS-DMA in R", 512, blocks, src, out, cyc);
         run<4, 32, 8, 2, false, false>("ping-pong, 32 MFMA, 8 ds_read + 2 LDS-DMA in R", 512, blocks, src, out, cyc);
         run<4, 32, 8, 4, false, false>("ping-pong, 32 MFMA, 8 ds_read + 4 LDS-DMA in R", 512, blocks, src, out, cyc);
