@@ -10,7 +10,11 @@
  * Conventions
  *   - plain C: device pointers + sizes, no torch / C++ types. `stream` is a hipStream_t passed
  *     as void* (NULL = the default stream). All calls are asynchronous on that stream and
- *     re-entrant per stream; the library keeps no per-call global state.
+ *     re-entrant per stream. Process-wide state (all of it advisory, none of it changes a result): the CU budget
+ *     (rsu_set_cu_budget), the tile-shape tuning switch and its table of measured choices (rsu_set_autotune; the FIRST call of
+ *     a new conv geometry synchronises the device and times the candidate shapes), and one page of zeros per device.
+ *   - devices: one process drives one GPU (torch.distributed, one rank per device). The HIP current device must be the device
+ *     the stream and the pointers belong to (the Python host calls torch.cuda.set_device); tensors stay below 2 GiB each.
  *   - activations: NHWC, bfloat16 ("bf16", the storage type of the fast path), raw uint16 bits.
  *     Channel counts of bf16 tensors must be multiples of 8 (16-byte pieces).
  *   - parameters / gradients / optimizer state: float32 in the reference's own layouts: conv
@@ -210,6 +214,42 @@ int rsu_extract_tiles(const float* imgs, float* tiles, int nimg, int H, int S, i
 int rsu_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, long t0,
                     long ntiles, rsu_stream_t stream);
 int rsu_overlap_finish(const float* acc, const float* hits, float* out, long n, rsu_stream_t stream);
+
+/* ---- post-processing wire format (src/images.py) and metric counters (src/summary.py) ------ */
+/* images.py:256-266 quantize_mask: per patch_size block of masks f32 [nimg][S][S] (channel axis squeezed), label =
+ * mean(mask >= 0.5) > threshold, written over the block of `out` (may alias masks). patch_size <= 64. */
+int rsu_quantize_mask(const float* masks, float* out, int nimg, int S, int patch_size, float threshold, rsu_stream_t stream);
+/* images.py:88-99 labels_for_patches over images.py:35-85 extract_patches(masks, patch_size): labels int64
+ * [nimg][S/ps][S/ps] in the reference's patch order (x outer, y inner), label = mean(patch) > threshold. */
+int rsu_labels_for_patches(const float* masks, int64_t* labels, int nimg, int S, int patch_size, float threshold,
+                           rsu_stream_t stream);
+/* summary.py:141-147 tf.metrics.accuracy / recall / precision keep running counts: counts[0..3] += TP, FP, FN, TN of n
+ * int64 {0,1} labels (caller zeroes `counts` where the reference runs tf.local_variables_initializer()). */
+int rsu_confusion_counts(const int64_t* predictions, const int64_t* labels, long n, unsigned long long* counts,
+                         rsu_stream_t stream);
+
+/* ---- static shape table (tf_aerial_images.py:133-145 build_graph fixes every shape up front) ---------- */
+#define RSU_OP_COLOR_ADJUST 0 /* unet.py:22-23 */
+#define RSU_OP_CONV3X3 1      /* unet.py:34-45, 88-91 (dilation 1 or 2; nsrc > 1: virtually concatenated crops) */
+#define RSU_OP_MAXPOOL 2      /* unet.py:52 */
+#define RSU_OP_CONVT2X2 3     /* unet.py:67-68 */
+#define RSU_OP_HEAD 4         /* unet.py:95 + tf_aerial_images.py:147-148 */
+typedef struct {
+    int kind, level;          /* RSU_OP_*; block index as in the reference's scope names (conv_<level>) */
+    int Hin, Win, Cin;        /* input window (of every source) and total input channels */
+    int Hout, Wout, Cout;
+    int dilation, nsrc;
+} rsu_plan_row_t;
+typedef struct {
+    int input_size;           /* unet.input_size_needed(patch_size, num_layers) */
+    long num_params;          /* every variable unet.forward creates (the dead level L-1 dilated pair included) */
+    long activation_elems;    /* bf16 elements of all op outputs for `batch` patches */
+    size_t workspace_floats;  /* largest scratch any backward entry point of this network asks for */
+} rsu_plan_totals_t;
+/* Ops of unet.forward in execution order for a (num_layers, root_size, patch_size, dilated) network: a binder needs no shape
+ * arithmetic of its own. rows may be NULL (count only); RSU_ENOMEM when capacity is too small (nrows still set). */
+int rsu_plan(int num_layers, int root_size, int patch_size, int dilated, int batch, rsu_plan_row_t* rows, int capacity,
+             int* nrows, rsu_plan_totals_t* totals);
 
 #ifdef __cplusplus
 }

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
                 int vv = lane + it;
                 int sc = __builtin_amdgcn_readfirstlane(it);
 #pragma unroll
-                for (int d = 0; d < (AGPR ? 0 : 10); ++d)
+                for (int d = 0; d < (AGPR ? 0 : (NM == 48 ? 10 : NM)); ++d)
                     asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5" : "+v"(vv), "+s"(sc));
                 asm volatile("" ::"v"(vv), "s"(sc));
 #pragma unroll
@@ -190,7 +190,7 @@ static void run(const char* name, int threads, int blocks, const bf16x8* src, fl
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> hl(blocks * 8);
     hipMemcpy(hl.data(), cyc, hl.size() * 8, hipMemcpyDeviceToHost);
-    const double flops = (double)blocks * (threads / 64) * long_iters * NM * 16384.0;
+    const double flops = (double)blocks * (threads / 64) * long_iters * (MODE == 6 ? 48 : NM) * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
     const double ghz = (double)hl[0] / (ms * 1e-3) / 1e9;  // counter ticks per second over the long run
     hipLaunchKernelGGL((probe<MODE, NM, NR, ND, BIG, AGPR>), dim3(blocks), dim3(threads), 96 * 1024, 0, src, out, cyc, iters, threads);
@@ -200,7 +200,7 @@ static void run(const char* name, int threads, int blocks, const bf16x8* src, fl
     const int waves = threads / 64;
     // MFMA work per SIMD per round: waves/4 waves x NM MFMAs x 16 cycles; ping-pong modes run 2 rounds (G0's and G1's) per iteration
     const double per_iter = (double)h[0] / iters;
-    const double ideal = MODE >= 2 ? 2.0 * NM * 16.0 : (double)(waves > 4 ? waves / 4 : 1) * NM * 16.0;
+    const double ideal = MODE == 6 ? 1536.0 : MODE >= 2 ? 2.0 * NM * 16.0 : (double)(waves > 4 ? waves / 4 : 1) * NM * 16.0;
     printf("%-52s blocks %3d  cyc/iter %8.1f  ideal %5.0f  util %5.1f %% | wall %7.1f TFLOP/s, counter %.2f GHz\n", name, blocks, per_iter, ideal,
            100.0 * ideal / per_iter, tf, ghz);
 }
@@ -239,6 +239,10 @@ int main() {
         run<6, 48, 8, 0, false, false>("kernel-like phase: 48 MFMA | 8 ds_read + 30 VALU + 40 SALU", 512, blocks, src, out, cyc);
         run<6, 48, 0, 0, false, false>("kernel-like phase: 48 MFMA | 0 ds_read + 30 VALU + 40 SALU", 512, blocks, src, out, cyc);
         run<6, 48, 0, 6, false, true>("kernel-like phase: 48 MFMA | 6 LDS-DMA only", 512, blocks, src, out, cyc);
+        run<6, 3, 24, 4, false, false>("lean phase: 48 MFMA | 24 ds_read + 21 ALU + 4 LDS-DMA", 512, blocks, src, out, cyc);
+        run<6, 3, 24, 6, false, false>("lean phase: 48 MFMA | 24 ds_read + 21 ALU + 6 LDS-DMA", 512, blocks, src, out, cyc);
+        run<6, 5, 24, 4, false, false>("lean phase: 48 MFMA | 24 ds_read + 35 ALU + 4 LDS-DMA", 512, blocks, src, out, cyc);
+        run<6, 3, 24, 2, false, false>("lean phase: 48 MFMA | 24 ds_read + 21 ALU + 2 LDS-DMA", 512, blocks, src, out, cyc);
         run<6, 48, 24, 3, false, false>("kernel-like phase + 3 LDS-DMA pieces per wave", 512, blocks, src, out, cyc);
         run<6, 48, 24, 6, false, false>("kernel-like phase + 6 LDS-DMA pieces per wave", 512, blocks, src, out, cyc);
         run<4, 16, 8, 2, false, false>("ping-pong, 16 MFMA, 8 ds_read + 2 LDS-DMA in R", 512, blocks, src, out, cyc);

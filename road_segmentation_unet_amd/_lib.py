@@ -16,6 +16,16 @@ class RsuSrc(ctypes.Structure):
     _fields_ = [("ptr", _vp), ("H", _i), ("W", _i), ("C", _i), ("oy", _i), ("ox", _i)]
 
 
+class RsuPlanRow(ctypes.Structure):
+    """rsu_plan_row_t"""
+    _fields_ = [(n, _i) for n in ("kind", "level", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "dilation", "nsrc")]
+
+
+class RsuPlanTotals(ctypes.Structure):
+    """rsu_plan_totals_t"""
+    _fields_ = [("input_size", _i), ("num_params", _l), ("activation_elems", _l), ("workspace_floats", _sz)]
+
+
 _PS = ctypes.POINTER(RsuSrc)
 _PI = ctypes.POINTER(ctypes.c_int)
 
@@ -64,6 +74,10 @@ SIGNATURES = {
     "rsu_extract_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_finish": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "rsu_quantize_mask": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "rsu_labels_for_patches": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
+    "rsu_confusion_counts": (_i, [_vp, _vp, _l, _vp, _vp]),
+    "rsu_plan": (_i, [_i, _i, _i, _i, _i, ctypes.POINTER(RsuPlanRow), _i, _PI, ctypes.POINTER(RsuPlanTotals)]),
 }
 
 _lib = None

@@ -13,9 +13,9 @@ import numpy as np
 
 
 def build_parser():
-    from .model import FLAG_DEFS
+    from .model import EXTRA_FLAG_DEFS, FLAG_DEFS
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    for name, typ, default, helptext in FLAG_DEFS:
+    for name, typ, default, helptext in FLAG_DEFS + EXTRA_FLAG_DEFS:
         if typ is bool:
             ap.add_argument("--" + name, nargs="?", const=True, default=default,
                             type=lambda s: s.lower() in ("1", "true", "t", "yes", "y"), help=helptext)
@@ -36,6 +36,7 @@ def main(argv=None):
     import torch.distributed as dist
     from . import hostio
     from .model import ConvolutionalModel
+    from .pool import DevicePatchPool
     from .unet import input_size_needed
     opts = parse_options(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
@@ -58,17 +59,46 @@ def main(argv=None):
         input_size = input_size_needed(opts.patch_size, opts.num_layers)
         offset = int((input_size - opts.patch_size) / 2)
         extended = hostio.expand_and_rotate(train_images, opts.rotation_angles, offset)
-        patches = hostio.extract_patches(extended, patch_size=input_size, predict_patch_size=opts.patch_size, stride=opts.stride)
-        print("Train on {} patches of size {}x{}".format(patches.shape[0], patches.shape[1], patches.shape[2]))
         gt_exp = hostio.expand_and_rotate(train_groundtruth, opts.rotation_angles, 0)
-        labels_patches = hostio.extract_patches(gt_exp, patch_size=opts.patch_size, stride=opts.stride)
-        print("Train on {} groundtruth patches of size {}x{}".format(*labels_patches.shape[:3]))
+        if opts.device_patch_pool:
+            # the reference's extract_patches arrays as an index over the rotated images, resident in HBM (pool.DevicePatchPool):
+            # same patches, same order, no 30-GB float64 pool on the host and no upload per step
+            patches = DevicePatchPool(extended, gt_exp, input_size, opts.patch_size, opts.stride, device=model.net.device,
+                                      augment=opts.d4_augmentation, seed=opts.seed)
+            labels_patches = None
+            print("Train on {} patches of size {}x{}".format(patches.shape[0], patches.shape[1], patches.shape[2]))
+            print("Train on {} groundtruth patches of size {}x{}".format(patches.shape[0], opts.patch_size, opts.patch_size))
+        else:
+            patches = hostio.extract_patches(extended, patch_size=input_size, predict_patch_size=opts.patch_size, stride=opts.stride)
+            print("Train on {} patches of size {}x{}".format(patches.shape[0], patches.shape[1], patches.shape[2]))
+            labels_patches = hostio.extract_patches(gt_exp, patch_size=opts.patch_size, stride=opts.stride)
+            print("Train on {} groundtruth patches of size {}x{}".format(*labels_patches.shape[:3]))
+        summary = model._ensure_summary()
+        if summary is not None:
+            summary.add_to_eval_patch_summary(train_groundtruth)
         for i in range(opts.num_epoch):
             print("==== Train epoch: {} ====".format(i))
+            if summary is not None:
+                summary.reset()  # tf.local_variables_initializer().run(): reset scores
             stats = model.train(patches, labels_patches, train_images, train_groundtruth)
             if rank == 0:
                 print("\nepoch {} : {}".format(i, stats))
             model.save(i)
+
+    if opts.eval_train:
+        print("Evaluate Test")
+        eval_images, eval_groundtruth = hostio.load_train_data(opts.train_data_dir)
+        pred_masks = model.predict_batchwise(eval_images, opts.pred_batch_size)
+        if rank == 0:
+            pred_labels = ((pred_masks > 0.5) * 1).squeeze(-1)
+            pred_overlays = hostio.overlays(eval_images, pred_masks, fade=0.5)
+            overlapped = hostio.overlap_pred_true(pred_labels, eval_groundtruth)
+            error = hostio.overlapp_error(pred_labels, eval_groundtruth)
+            hostio.save_all(pred_labels, opts.eval_data_dir, "eval_binary_pred_{:03d}.png", greyscale=True)
+            hostio.save_all(pred_masks, opts.eval_data_dir, "eval_probability_pred_{:03d}.png", greyscale=True)
+            hostio.save_all(pred_overlays, opts.eval_data_dir, "eval_overlays_pred_{:03d}.png")
+            hostio.save_all(overlapped, opts.eval_data_dir, "eval_confusion_{:03d}.png")
+            hostio.save_all(error, opts.eval_data_dir, "eval_orror_{:03d}.png", greyscale=True)
 
     if opts.eval_data_dir and not opts.eval_train:
         print("Running inference on eval data {}".format(opts.eval_data_dir))
@@ -76,10 +106,13 @@ def main(argv=None):
         start = time.time()
         masks = model.predict_batchwise(eval_images, opts.pred_batch_size)
         print("Prediction time:{} mins".format((time.time() - start) / 60))
-        masks = hostio.quantize_mask(masks, patch_size=hostio.IMG_PATCH_SIZE, threshold=hostio.FOREGROUND_THRESHOLD)
+        masks = model.quantize_mask(masks, patch_size=hostio.IMG_PATCH_SIZE, threshold=hostio.FOREGROUND_THRESHOLD)
         if rank == 0:
             save_dir = os.path.abspath(os.path.join(opts.save_path, model.experiment_name))
+            overlays = hostio.overlays(eval_images, masks, fade=0.4)
+            hostio.save_all(overlays, save_dir)
             hostio.save_submission_csv(masks, save_dir, hostio.IMG_PATCH_SIZE)
+            model.save_as(save_dir + "-model.chkpt")  # the model used for the submission
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0

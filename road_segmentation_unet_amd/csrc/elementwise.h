@@ -34,3 +34,5 @@ int ew_pack_blocks(const PackParams& pp);
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st);
+hipError_t ew_block_label(const float* mask, float* out, int64_t* labels, int nimg, int S, int ps, float thr, int mode, hipStream_t st);
+hipError_t ew_confusion(const int64_t* pred, const int64_t* truth, long n, unsigned long long* counts, hipStream_t st);

@@ -776,3 +776,65 @@ hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, lo
     hipLaunchKernelGGL(k_overlap_finish, dim3(grid_for(n, 256)), dim3(256), 0, st, acc, hits, out, n);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// post-processing (src/images.py:88-99, 256-266; src/summary.py:134-147)
+// ---------------------------------------------------------------------------------------------
+// One 256-thread workgroup per patch_size x patch_size block of a mask [nimg][S][S] (patch_size <= 64): the block statistic
+//   mode 0 (quantize_mask, images.py:256-266):       label = mean(mask >= 0.5) > threshold, written over the whole block of `out`
+//   mode 1 (labels_for_patches, images.py:88-99):    label = mean(mask) > threshold, written to labels[img][bx][by] (x outer: the
+//                                                    patch order of extract_patches) as int64
+// Blocks cut by the image edge average over the pixels they hold (numpy slicing does the same).
+__global__ void __launch_bounds__(256) k_block_label(const float* __restrict__ mask, float* __restrict__ out, int64_t* __restrict__ labels,
+                                                     int S, int ps, int nb, float thr, int mode) {
+    const int b = blockIdx.x, by = b % nb, bx = (b / nb) % nb, img = b / (nb * nb);
+    const int y0 = by * ps, x0 = bx * ps;
+    const int hh = min(ps, S - y0), ww = min(ps, S - x0);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < hh * ww; i += 256) {
+        const float v = mask[((long)img * S + y0 + i / ww) * S + x0 + i % ww];
+        sum += mode == 0 ? (v >= 0.5f ? 1.f : 0.f) : v;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float lab = (red[0] / (float)(hh * ww)) > thr ? 1.f : 0.f;
+    if (mode == 0) {
+        for (int i = threadIdx.x; i < hh * ww; i += 256) out[((long)img * S + y0 + i / ww) * S + x0 + i % ww] = lab;
+    } else if (threadIdx.x == 0) {
+        labels[((long)img * nb + bx) * nb + by] = (int64_t)lab;
+    }
+}
+hipError_t ew_block_label(const float* mask, float* out, int64_t* labels, int nimg, int S, int ps, float thr, int mode, hipStream_t st) {
+    const int nb = (S + ps - 1) / ps;
+    hipLaunchKernelGGL(k_block_label, dim3(nimg * nb * nb), dim3(256), 0, st, mask, out, labels, S, ps, nb, thr, mode);
+    return hipGetLastError();
+}
+// tf.metrics.{accuracy, recall, precision} counters (summary.py:141-147): counts[0..3] += TP, FP, FN, TN over n int64 labels
+__global__ void __launch_bounds__(256) k_confusion(const int64_t* __restrict__ pred, const int64_t* __restrict__ truth, long n,
+                                                   unsigned long long* __restrict__ counts) {
+    unsigned c[4] = {0, 0, 0, 0};
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int pr = pred[i] != 0, t = truth[i] != 0;
+        ++c[pr ? (t ? 0 : 1) : (t ? 2 : 3)];
+    }
+    __shared__ unsigned red[4][256];
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = c[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)red[threadIdx.x][0]);
+}
+hipError_t ew_confusion(const int64_t* pred, const int64_t* truth, long n, unsigned long long* counts, hipStream_t st) {
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_confusion, dim3(grid), dim3(256), 0, st, pred, truth, n, counts);
+    return hipGetLastError();
+}

@@ -41,12 +41,8 @@ struct IgFwdParams {
     TileGeo g;
 };
 
-// config ids (see igemm_fwd.hip for the tile shapes)
-enum { IGF_CFG_64x256 = 0, IGF_CFG_128x256 = 1, IGF_CFG_128x128 = 2, IGF_CFG_128x64 = 3, IGF_CFG_64x128 = 4, IGF_NCFG = 5 };
 struct IgFwdCfgInfo { int TN, TM, threads; };
-IgFwdCfgInfo igemm_fwd_cfg_info(int cfg);
-size_t igemm_fwd_lds_bytes(int cfg, int ntap, int npix_max);
-// second generation (persistent, counted-vmcnt pipeline; igemm_fwd2.hip)
+// persistent, counted-vmcnt pipeline (igemm_fwd2.hip)
 enum { IGF2_CFG_128x256 = 0, IGF2_CFG_64x512 = 1, IGF2_CFG_128x128 = 2, IGF2_CFG_64x256 = 3, IGF2_CFG_128x192 = 4, IGF2_CFG_64x384 = 5,
        IGF2_CFG_128x320 = 6, IGF2_CFG_64x640 = 7, IGF2_NCFG = 8 };
 IgFwdCfgInfo igemm_fwd2_cfg_info(int cfg);
@@ -56,8 +52,6 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x
 // third generation (ping-pong wave groups; igemm_pp.hip): 3x3 taps, stride 1; tile shapes, LDS budget and results as igemm_fwd2
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
-// ntap in {1,4,9}
-hipError_t igemm_fwd_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // igemm_wgrad: slab[z][tap][cs_off+cs][cf] = sum_{pix in split z} S[n][pix*stride + tap*dil][cs] * F[n][pix][cf]

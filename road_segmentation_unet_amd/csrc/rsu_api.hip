@@ -17,14 +17,18 @@ static void rsu_set_hip_error(int e) { g_last_hip_error.store(e); }
 
 __device__ uint4 g_zero_page_dev[256];  // 4 KiB, zero-initialised
 
+// (one copy of the page per device: the address is looked up for the CURRENT device -- the caller's stream must belong to it, see
+// rsu.h "devices")
 static const void* zero_page() {
-    static void* ptr = nullptr;
-    if (!ptr) {
+    static void* ptr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ptr[dev]) {
         void* q = nullptr;
         if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page_dev)) != hipSuccess) return nullptr;
-        ptr = q;
+        ptr[dev] = q;
     }
-    return ptr;
+    return ptr[dev];
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -78,47 +82,8 @@ extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input
 // ---------------------------------------------------------------------------------------------
 // tile planning
 // ---------------------------------------------------------------------------------------------
-// Choose the strip width for a Ho x Wo pixel grid cut into TM-pixel tiles; npix_cap = LDS pixels available.
-static bool plan_geo(TileGeo& best, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap) {
-    if (Ho < 1 || Wo < 2) return false;
-    int cands[6];
-    int nc = 0;
-    if (Wo <= 96) cands[nc++] = Wo;
-    cands[nc++] = 64;
-    cands[nc++] = 32;
-    cands[nc++] = 16;
-    cands[nc++] = 8;
-    double best_cost = 1e30;
-    bool found = false;
-    for (int i = 0; i < nc; ++i) {
-        const int SW = cands[i];
-        if (SW > Wo && SW != cands[0]) continue;
-        if (SW < 2) continue;
-        TileGeo g;
-        g.SW = SW;
-        g.nstrips = cdiv(Wo, SW);
-        g.tiles_per_strip = cdiv(Ho * SW, TM);
-        int rows = (TM % SW == 0) ? TM / SW : TM / SW + 2;
-        if (rows > Ho) rows = Ho;
-        const int R = (rows - 1) * stride + (kh - 1) * dil + 1;
-        g.CW = rup((SW - 1) * stride + (kw - 1) * dil + 1, 8);
-        g.npix_max = rup(R * g.CW, 32);
-        if (g.npix_max > npix_cap) continue;
-        g.inv_SW = magic32(SW);
-        g.inv_CW = magic32(g.CW);
-        const double waste = (double)g.nstrips * g.tiles_per_strip * TM / ((double)Ho * Wo);
-        const double halo = (double)g.npix_max / TM;
-        const double cost = waste * (1.0 + 0.05 * halo);
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = g;
-            found = true;
-        }
-    }
-    return found;
-}
-
-// Aligned variant for the second-generation kernels: SW is a power of two dividing TM; a tile is TM/SW full rows of a strip.
+// Strip width for a Ho x Wo pixel grid cut into aligned TM-pixel tiles: SW is a power of two dividing TM; a tile is TM/SW full rows
+// of a strip; npix_cap = LDS pixels available for the halo tile.
 static bool plan_geo_aligned(TileGeo& best, int& lsw_out, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap) {
     if (Ho < 1 || Wo < 1) return false;
     double best_cost = 1e30;
@@ -304,48 +269,22 @@ extern "C" int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsig
 // ---------------------------------------------------------------------------------------------
 // igemm_fwd family
 // ---------------------------------------------------------------------------------------------
-struct FwdPlan { int cfg; TileGeo g; int ncob; };
-static bool plan_fwd(FwdPlan& pl, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int force_cfg) {
-    static const int order64[] = {IGF_CFG_64x256, IGF_CFG_64x128};
-    static const int order128[] = {IGF_CFG_128x256, IGF_CFG_128x128, IGF_CFG_128x64};
-    const bool narrow = Cout <= 64;
-    const int* order = narrow ? order64 : order128;
-    const int norder = narrow ? 2 : 3;
-    bool have = false;
-    for (int i = 0; i < norder; ++i) {
-        const int cfg = force_cfg >= 0 ? force_cfg : order[i];
-        const IgFwdCfgInfo ci = igemm_fwd_cfg_info(cfg);
-        if (ci.TN == 0) return false;
-        const size_t wbytes = igemm_fwd_lds_bytes(cfg, ntap, 0);
-        const int cap = (int)((160 * 1024 - (long)wbytes) / 128);
-        TileGeo g;
-        if (!plan_geo(g, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) {
-            if (force_cfg >= 0) return false;
-            continue;
-        }
-        pl.cfg = cfg;
-        pl.g = g;
-        pl.ncob = cdiv(Cout, ci.TN);
-        have = true;
-        const long wgs = (long)N * g.nstrips * g.tiles_per_strip * pl.ncob;
-        if (force_cfg >= 0 || wgs >= 384) break;  // enough workgroups to fill 256 CUs; else try a smaller tile
-    }
-    return have;
-}
-
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
 struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
 static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
                       int force_cfg, bool shared_chip = false) {
     double best_cost = 1e300;
     bool have = false;
+    // pass 0: channel-block width matched to Cout; pass 1 (only when no such shape fits its halo tile into LDS -- the 2x2 stride-2
+    // taps of a narrow transposed conv need 4 x TM halo pixels in a four-slot ring): any width
+    for (int pass = 0; pass < 2 && !have; ++pass)
     for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
         if (force_cfg >= 0 && cfg != force_cfg) continue;
         if (igemm_fwd2_cfg_info(cfg).TN == 0) continue;  // retired ids
         if (force_cfg < 0 && (cfg == IGF2_CFG_128x320 || cfg == IGF2_CFG_64x640) && !env_int("RSU_CFG_320", 1)) continue;
         const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
-        if (Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
-        if (Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
+        if (pass == 0 && Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
+        if (pass == 0 && Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
         const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
         const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, ntap, 1) - fixed;  // 64 bytes x halo ring slots
         int cap = (int)((160 * 1024 - fixed) / per_pix);
@@ -400,20 +339,21 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     const int kh = ntap / kw;
     const long out_bytes = (long)N * oH * oW * outC * 2;
     const int gen = env_int("RSU_FWD_GEN", 3);
-    bool gen2 = gen >= 2 && out_bytes < 0x7ffffff0L;
+    // the kernels address every tensor through 32-bit byte offsets of a buffer descriptor: a tensor must stay below 2 GiB (split
+    // the batch otherwise -- L = 6, P = 388 reaches that at 29 patches per call)
+    if (out_bytes >= 0x7ffffff0L) return RSU_EINVAL;
     // RSU_FWD_GEN: 2 = igemm_fwd2 only; 3 (default) = the ping-pong kernel where it measured (or, untuned, is expected to be) faster;
     // 4 = the ping-pong kernel wherever it is built (tests)
     const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1;
     for (int i = 0; i < nsrc; ++i)
-        if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) gen2 = false;
-    FwdPlan pl;
+        if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) return RSU_EINVAL;
     Fwd2Plan pl2;
     int ktot = 0;
     for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * ntap;
     const int env_cfg = env_int("RSU_FWD2_CFG", -1);
     const bool shared_chip = pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0;
     // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
-    const bool tunable = gen2 && env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
+    const bool tunable = env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc, (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0),
                                 ostride, g_cu_budget.load() * 4 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
@@ -428,8 +368,10 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             tune_now = true;
         }
     }
-    bool use2 = gen2 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip);
-    if (!use2 && !plan_fwd(pl, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, env_int("RSU_FWD_CFG", -1))) return RSU_EINVAL;
+    if (!plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip)) {
+        // a shape forced through RSU_FWD2_CFG whose halo tile does not fit this geometry: plan freely instead
+        if (!(env_cfg >= 0 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip))) return RSU_EINVAL;
+    }
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
     p.nsrc = nsrc;
@@ -458,7 +400,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.dil = dil; p.stride = stride; p.pad = pad;
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
-    if (use2) {
+    {
         // untuned choice of the kernel generation: the ping-pong kernel on the 128-channel shapes (measured +5-10 % there; the
         // 64-channel shapes keep more halo offsets per wave than their registers hold)
         const bool pp = pp_ok && igemm_pp_has(pl2.cfg) &&
@@ -540,12 +482,6 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
         HIP_CHECK_RET(launch_persistent(pp, pl2.cfg, ntap, p, pl2.grid_x, gy, st));
         return RSU_OK;
     }
-    p.ncob = pl.ncob;
-    p.g = pl.g;
-    const long gx = (long)N * pl.g.nstrips * pl.g.tiles_per_strip * pl.ncob;
-    if (gx > 0x7fffffffL) return RSU_EINVAL;
-    HIP_CHECK_RET(igemm_fwd_launch(pl.cfg, ntap, p, (int)gx, gy, st));
-    return RSU_OK;
 }
 
 extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
@@ -661,6 +597,9 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
 
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
                      int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
+    // 32-bit byte offsets inside the kernel: both operand tensors must stay below 2 GiB (beyond that the offsets wrapped
+    // silently and only the weight gradients came out wrong)
+    if ((long)N * Hf * Wf * Cf * 2 >= 0x7ffffff0L || (long)N * S->H * S->W * S->C * 2 >= 0x7ffffff0L) return RSU_EINVAL;
     WgPlan pl;
     const int wide = wgrad_pick_cfg(cfg, Cf);
     if (wide != cfg && plan_wgrad(pl, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
@@ -812,4 +751,107 @@ extern "C" int rsu_overlap_finish(const float* acc, const float* hits, float* ou
     if (!acc || !hits || !out || n < 1) return RSU_EINVAL;
     HIP_CHECK_RET(ew_overlap_finish(acc, hits, out, n, (hipStream_t)stream));
     return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-processing wire format + metrics counters
+// ---------------------------------------------------------------------------------------------
+extern "C" int rsu_quantize_mask(const float* masks, float* out, int nimg, int S, int patch_size, float threshold, rsu_stream_t stream) {
+    if (!masks || !out || nimg < 1 || S < 1 || patch_size < 1 || patch_size > 64) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_block_label(masks, out, nullptr, nimg, S, patch_size, threshold, 0, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_labels_for_patches(const float* masks, int64_t* labels, int nimg, int S, int patch_size, float threshold,
+                                      rsu_stream_t stream) {
+    if (!masks || !labels || nimg < 1 || S < 1 || patch_size < 1 || patch_size > 64 || S % patch_size) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_block_label(masks, nullptr, labels, nimg, S, patch_size, threshold, 1, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_confusion_counts(const int64_t* predictions, const int64_t* labels, long n, unsigned long long* counts,
+                                    rsu_stream_t stream) {
+    if (!predictions || !labels || !counts || n < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_confusion(predictions, labels, n, counts, (hipStream_t)stream));
+    return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rsu_plan: the static shape table of unet.forward (src/unet.py:12-97) for a (num_layers, root_size, patch_size, dilated) network
+// ---------------------------------------------------------------------------------------------
+extern "C" int rsu_plan(int num_layers, int root_size, int patch_size, int dilated, int batch, rsu_plan_row_t* rows, int capacity,
+                        int* nrows, rsu_plan_totals_t* totals) {
+    if (num_layers < 1 || root_size < 8 || root_size % 8 || patch_size < 1 || batch < 1 || !nrows) return RSU_EINVAL;
+    int S = 0;
+    if (rsu_input_size_needed(patch_size, num_layers, &S) != RSU_OK) return RSU_EINVAL;
+    const int L = num_layers;
+    int n = 0;
+    long params = 0, act_elems = 0;
+    size_t ws = 0;
+    auto upd_ws = [&](size_t w) { if (w > ws) ws = w; };
+    auto add = [&](int kind, int level, int Hin, int Cin, int Cout, int Hout, int dil, int nsrc) {
+        if (rows && n < capacity) {
+            rsu_plan_row_t r;
+            r.kind = kind; r.level = level; r.Hin = Hin; r.Win = Hin; r.Cin = Cin; r.Cout = Cout; r.Hout = Hout; r.Wout = Hout;
+            r.dilation = dil; r.nsrc = nsrc;
+            rows[n] = r;
+        }
+        ++n;
+        act_elems += (long)batch * Hout * Hout * Cout;
+    };
+    auto conv_params = [&](int k, int cin, int cout) { params += (long)k * k * cin * cout + cout; };
+    add(RSU_OP_COLOR_ADJUST, 0, S, 3, 3, S, 1, 1);
+    conv_params(1, 3, 3);
+    int h = S, nf = root_size, cin = 3;
+    for (int i = 0; i < L; ++i) {
+        if (dilated) {  // unet.py:32-39: the dilated twin block (built at every level; the level L-1 pair is never consumed)
+            conv_params(3, cin, nf);
+            conv_params(3, nf, nf);
+            if (i < L - 1) {
+                add(RSU_OP_CONV3X3, i, h, cin, nf, h - 4, 2, 1);
+                add(RSU_OP_CONV3X3, i, h - 4, nf, nf, h - 8, 2, 1);
+                if (cin != 3) upd_ws(rsu_conv2d_bwd_weight_ws_floats(cin, cin, nf));
+                upd_ws(rsu_conv2d_bwd_weight_ws_floats(nf, nf, nf));
+            }
+        }
+        add(RSU_OP_CONV3X3, i, h, cin, nf, h - 2, 1, 1);
+        add(RSU_OP_CONV3X3, i, h - 2, nf, nf, h - 4, 1, 1);
+        conv_params(3, cin, nf);
+        conv_params(3, nf, nf);
+        if (cin != 3) upd_ws(rsu_conv2d_bwd_weight_ws_floats(cin, cin, nf)); else upd_ws(rsu_conv_first_bwd_ws_floats(nf));
+        upd_ws(rsu_conv2d_bwd_weight_ws_floats(nf, nf, nf));
+        if (i < L - 1) {
+            if ((h - 4) % 2) return RSU_EINVAL;
+            add(RSU_OP_MAXPOOL, i, h - 4, nf, nf, (h - 4) / 2, 1, 1);
+            h = (h - 4) / 2;
+            cin = nf;
+            nf *= 2;
+        }
+    }
+    h -= 4;
+    for (int i = 0; i < L - 1; ++i) {
+        nf /= 2;
+        const int j = L + i, nsrc = dilated ? 3 : 2;
+        add(RSU_OP_CONVT2X2, j, h, 2 * nf, nf, 2 * h, 1, 1);
+        params += (long)4 * nf * 2 * nf + nf;
+        upd_ws(rsu_convT2x2_bwd_weight_ws_floats(2 * nf, nf));
+        h *= 2;
+        add(RSU_OP_CONV3X3, j, h, nsrc * nf, nf, h - 2, 1, nsrc);  // concat [skip, (dilated skip), up] never materialised
+        add(RSU_OP_CONV3X3, j, h - 2, nf, nf, h - 4, 1, 1);
+        conv_params(3, nsrc * nf, nf);
+        conv_params(3, nf, nf);
+        upd_ws(rsu_conv2d_bwd_weight_ws_floats(nsrc * nf, nf, nf));
+        upd_ws(rsu_conv2d_bwd_weight_ws_floats(nf, nf, nf));
+        h -= 4;
+    }
+    if (h != patch_size) return RSU_EINVAL;
+    add(RSU_OP_HEAD, 2 * L - 1, h, nf, 2, h, 1, 1);
+    conv_params(1, nf, 2);
+    upd_ws(rsu_head_ws_floats((long)batch * h * h, nf));
+    *nrows = n;
+    if (totals) {
+        totals->input_size = S;
+        totals->num_params = params;
+        totals->activation_elems = act_elems;
+        totals->workspace_floats = ws;
+    }
+    return (rows && n > capacity) ? RSU_ENOMEM : RSU_OK;
 }

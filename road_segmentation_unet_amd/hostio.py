@@ -11,6 +11,11 @@ IMG_PATCH_SIZE = 16         # src/constants.py:2
 PIXEL_DEPTH = 255           # src/constants.py:5
 
 
+def img_float_to_uint8(img):
+    """images.py:19-21"""
+    return (np.asarray(img) * PIXEL_DEPTH).round().astype(np.uint8)
+
+
 def load(directory):
     """images.py:24-32: every *.png of `directory`, sorted, as float32 in [0,1]: [n, H, W(, C)]"""
     from PIL import Image
@@ -113,3 +118,62 @@ def save_submission_csv(masks, path, patch_size=IMG_PATCH_SIZE):
         for r in submission_rows(masks, patch_size):
             f.write(r + "\n")
     return filename
+
+
+def overlays(imgs, masks, fade=0.95):
+    """images.py:102-128: the masks in red over the images, alpha = mask * fade (PIL alpha_composite); uint8 [n, W, H, 4]"""
+    from PIL import Image
+    imgs, masks = np.asarray(imgs), np.asarray(masks)
+    num_images, im_height, im_width, num_channel = imgs.shape
+    assert num_channel == 3, 'Predict image should be colored'
+    imgs8 = img_float_to_uint8(imgs)
+    masks8 = img_float_to_uint8(masks.squeeze())
+    masks_red = np.zeros((num_images, im_height, im_width, 4), dtype=np.uint8)
+    masks_red[:, :, :, 0] = 255
+    masks_red[:, :, :, 3] = masks8 * fade
+    results = np.zeros((num_images, im_width, im_height, 4), dtype=np.uint8)
+    for i in range(num_images):
+        x = Image.fromarray(imgs8[i]).convert('RGBA')
+        y = Image.fromarray(masks_red[i])
+        results[i] = np.array(Image.alpha_composite(x, y))
+    return results
+
+
+def overlap_pred_true(pred, true):
+    """images.py:282-293: prediction in the red, ground truth in the green channel"""
+    pred, true = np.asarray(pred), np.asarray(true)
+    num_images, im_height, im_width = pred.shape
+    out = np.zeros((num_images, im_height, im_width, 3), dtype=np.uint8)
+    out[:, :, :, 0] = img_float_to_uint8(pred)
+    out[:, :, :, 1] = img_float_to_uint8(true)
+    return out
+
+
+def overlapp_error(pred, true):
+    """images.py:296-309: white where prediction and ground truth agree"""
+    pred, true = np.asarray(pred), np.asarray(true)
+    num_images, im_height, im_width = pred.shape
+    agree = np.logical_not(np.logical_xor(img_float_to_uint8(true).astype(bool), img_float_to_uint8(pred).astype(bool)))
+    err = img_float_to_uint8(agree * 1)
+    return np.repeat(err[..., None], 3, axis=-1)
+
+
+def save_all(images, directory, format_="images_{:03d}.png", greyscale=False):
+    """images.py:185-205 (matplotlib.image.imsave: 2-D arrays go through the colour map, normalised to their own range)"""
+    import matplotlib as mpl
+    import matplotlib.image as mpimg
+    images = np.asarray(images)
+    os.makedirs(directory, exist_ok=True)
+    if images.ndim == 4 and images.shape[-1] == 1:
+        images = images.squeeze(-1)
+    cmap = "gray" if greyscale else mpl.rcParams.get("image.cmap")
+    for n in range(images.shape[0]):
+        mpimg.imsave(os.path.join(directory, format_.format(n + 1)), images[n], cmap=cmap)
+
+
+def img_to_label_patches(img, patch_size=IMG_PATCH_SIZE):
+    """summary.py:134-139 on the host, quirk included: the [n] label vector resized in place to [n, ps, ps] (zero filled)"""
+    lab = labels_for_patches(extract_patches(np.asarray(img), patch_size))
+    out = np.zeros(lab.shape[0] * patch_size * patch_size, dtype=lab.dtype)
+    out[:lab.shape[0]] = lab
+    return out.reshape(lab.shape[0], patch_size, patch_size)

@@ -14,9 +14,12 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import hostio
 from . import images as dimages
 from ._lib import call
 from .dist import GradBucketer, shard_indices, tune_overlap
+from .pool import BatchUploader, DevicePatchPool, PatchPool
+from .summary import Summary
 from .unet import UNet, input_size_needed
 
 # (name, type, default, help) -- tf_aerial_images.py:15-46, same order
@@ -54,12 +57,20 @@ FLAG_DEFS = [
 ]
 
 
+# options the reference does not have (kept apart from its 30 flags): where the training patches live and the D4 augmentation
+EXTRA_FLAG_DEFS = [
+    ("device_patch_pool", bool, True, "Keep the rotated training images in HBM and cut the patches of a batch on the GPU"),
+    ("d4_augmentation", bool, False, "Stochastic flips / transpose / rot90 per training sample on the GPU (what the reference's "
+                                     "--image_augmentation subgraph intended; that flag itself stays without effect, as in the reference)"),
+]
+
+
 class Options(object):
     """Options used by our model (tf_aerial_images.py:51-84). Construct with keyword overrides of the flag defaults;
     `rotation_angles` accepts the flag string "a,b,c" and is stored as a list of ints like the reference."""
 
     def __init__(self, **overrides):
-        for name, _typ, default, _help in FLAG_DEFS:
+        for name, _typ, default, _help in FLAG_DEFS + EXTRA_FLAG_DEFS:
             setattr(self, name, default)
         for k, v in overrides.items():
             if not hasattr(self, k):
@@ -94,6 +105,8 @@ class ConvolutionalModel:
         self.local_batch = opts.batch_size // self.world
         if device is None:
             device = "cuda:%d" % (opts.gpu if opts.gpu >= 0 else int(os.environ.get("LOCAL_RANK", "0")))
+        if torch.device(device).type == "cuda":
+            torch.cuda.set_device(torch.device(device))  # the library works on the HIP current device (rsu.h "devices")
         # the reference's graph is static in (batch, patch): one UNet serves training and (zero-padded) prediction batches
         self.net = UNet(opts.num_layers, opts.root_size, opts.dilated_layers, self.local_batch, opts.patch_size, device=device,
                         params=params, seed=opts.seed, training=True)
@@ -101,6 +114,11 @@ class ConvolutionalModel:
         self._bucketer = None
         self._exchange_tuned = False
         self.exchange_schedule = None
+        self._uploader = None
+        # summaries (tf_aerial_images.py:126-131,158-163): scalars loss + learning_rate per step, streaming train / eval scores
+        # (created by the first train() call, so that prediction-only models leave no log directory behind)
+        self._summary = None
+        self._pending_scalars = []
         if self.world > 1:
             self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
             self._bucketer.extra_streams = [self.net.wstream]
@@ -112,10 +130,16 @@ class ConvolutionalModel:
     # ------------------------------------------------------------------ training
     def train_step(self, patches, labels):
         """One session.run([train, loss, predictions]) (tf_aerial_images.py:241-244) on this rank's shard.
-        patches [b,S,S,3] float, labels [b,P,P] in {0,1}; returns (global mean loss tensor, predictions [b,P,P] device tensor)."""
+        patches [b,S,S,3] float, labels [b,P,P] in {0,1}; returns (global mean loss tensor, predictions [b,P,P] device tensor).
+        (Synchronous upload: the train() loop stages its batches one step ahead instead, see pool.BatchUploader.)"""
+        net = self.net
+        net.x.copy_(torch.as_tensor(np.asarray(patches, dtype=np.float32)).to(net.device))
+        net.labels.copy_(torch.as_tensor(np.asarray(labels)).to(net.device, torch.int64))
+        return self._run_step()
+
+    def _run_step(self):
+        """forward + loss + backward + gradient exchange + Momentum on the batch held in net.x / net.labels"""
         opts, net = self._options, self.net
-        net.x.copy_(torch.as_tensor(patches).to(net.device, torch.float32))
-        net.labels.copy_(torch.as_tensor(labels).to(net.device, torch.int64))
         if self._bucketer is not None and not self._exchange_tuned:
             # first step of a data-parallel run: time forward + backward + exchange (no optimizer step, so the trajectory is
             # untouched) under both schedules and keep the faster one (dist.tune_overlap)
@@ -140,31 +164,92 @@ class ConvolutionalModel:
         net.apply_momentum(opts.lr, opts.momentum)
         return loss, net.prob
 
+    def _ensure_summary(self):
+        opts = self._options
+        if self._summary is None and self.rank == 0 and getattr(opts, "logdir", None):
+            self._summary = Summary(opts, self._session, os.path.join(opts.logdir, self.experiment_name), device=self.net.device)
+            self._summary.initialize_eval_summary()
+            self._summary.initialize_train_summary()
+            self._summary.initialize_overlap_summary()
+            self._summary.initialize_missclassification_summary()
+            self.summary_op = self._summary.get_summary_op({"loss": None, "learning_rate": None})
+        return self._summary
+
+    def _flush_scalars(self):
+        """the per-step scalars are kept as device tensors and written in batches: reading them back every step would serialise
+        the host with the GPU (the reference's session.run does exactly that)"""
+        if self._summary is not None:
+            for step, loss_t, err_t, total, lr in self._pending_scalars:
+                self._summary.add({"loss": float(loss_t), "learning_rate": lr}, global_step=step)
+                self._summary.add_to_pixel_missclassification_summary(float(err_t), total, step)
+        self._pending_scalars = []
+
     def train(self, patches, labels_patches, imgs, labels):
         """Train the model for one epoch (tf_aerial_images.py:212-269): binarise labels at 0.5, shuffle with np.random,
-        `for offset in range(0, N - batch_size, batch_size)` (the final batch is dropped even when full)."""
-        opts = self._options
-        labels_patches = (np.asarray(labels_patches) >= 0.5) * 1.
+        `for offset in range(0, N - batch_size, batch_size)` (the final batch is dropped even when full).
+        `patches` is the reference's [N,S,S,3] array (then `labels_patches` its [N,P,P] labels) or a pool.PatchPool /
+        pool.DevicePatchPool holding the same patches as an index (then `labels_patches` is ignored)."""
+        opts, net = self._options, self.net
+        self._ensure_summary()
+        pool = patches if isinstance(patches, PatchPool) else None
+        if pool is None:
+            labels_patches = (np.asarray(labels_patches) >= 0.5) * 1.
+        if labels is not None:
+            labels = (np.asarray(labels) >= 0.5) * 1.
         num_train_patches = patches.shape[0]
         indices = np.arange(0, num_train_patches)
         np.random.shuffle(indices)
-        num_errors = torch.zeros((), dtype=torch.float64, device=self.net.device)
+        num_errors = torch.zeros((), dtype=torch.float64, device=net.device)
         total = 0
         last = None
-        for batch_i, offset in enumerate(range(0, num_train_patches - opts.batch_size, opts.batch_size)):
+        offsets = list(range(0, num_train_patches - opts.batch_size, opts.batch_size))
+        device_pool = isinstance(pool, DevicePatchPool)
+        if not device_pool and self._uploader is None and net.device.type == "cuda":
+            self._uploader = BatchUploader(net)
+
+        def host_batch(offset):
             idx = shard_indices(indices, offset, opts.batch_size, self.rank, self.world)
-            loss, predictions = self.train_step(patches[idx], labels_patches[idx])
-            step = self.net.global_step
+            return pool.gather(idx) if pool is not None else (patches[idx], labels_patches[idx])
+
+        if offsets and not device_pool:
+            self._uploader.stage(0, *host_batch(offsets[0]))
+        for batch_i, offset in enumerate(offsets):
+            if device_pool:
+                pool.load_batch(shard_indices(indices, offset, opts.batch_size, self.rank, self.world), net.x, net.labels)
+            else:
+                self._uploader.commit(batch_i & 1)
+            loss, predictions = self._run_step()
+            if not device_pool and batch_i + 1 < len(offsets):
+                self._uploader.stage((batch_i + 1) & 1, *host_batch(offsets[batch_i + 1]))  # rides beside the step just launched
+            step = net.global_step
             if self.rank == 0:
                 print("Batch {} Step {}".format(batch_i, step), end="\r")
-            num_errors += (self.net.labels.to(torch.float64) - predictions.to(torch.float64)).abs().sum()  # soft error (:249)
+            num_errors += (net.labels.to(torch.float64) - predictions.to(torch.float64)).abs().sum()  # soft error (:249)
             total += opts.batch_size
             last = loss
+            if self._summary is not None:
+                self._pending_scalars.append((step, loss.clone(), num_errors.clone(), total, net.learning_rate(opts.lr)))
+                if len(self._pending_scalars) >= 64:
+                    self._flush_scalars()
+            # from time to time do full prediction on some images (tf_aerial_images.py:253-264)
             if step > 0 and step % opts.eval_every == 0 and imgs is not None:
-                masks = self.predict(imgs[:opts.num_eval_images])
+                images_to_predict = np.asarray(imgs)[:opts.num_eval_images]
+                masks = self.predict(images_to_predict)
                 if self.rank == 0:
-                    print("\nstep {} loss {:.5f} pixel-F1 on {} eval images {:.4f}".format(
-                        step, float(loss), opts.num_eval_images, pixel_f1(masks, np.asarray(labels)[:opts.num_eval_images])))
+                    f1 = pixel_f1(masks, labels[:opts.num_eval_images])
+                    print("\nstep {} loss {:.5f} pixel-F1 on {} eval images {:.4f}".format(step, float(loss), opts.num_eval_images, f1))
+                    if self._summary is not None:
+                        overlays = hostio.overlays(images_to_predict, masks)
+                        pred_masks = ((masks > 0.5) * 1).squeeze(-1)
+                        self._summary.add_to_eval_summary(masks, overlays, labels, step)
+                        self._summary.add_to_overlap_summary(labels[:opts.num_eval_images], pred_masks, step)
+            if step > 0 and step % opts.train_score_every == 0 and imgs is not None:
+                train_masks = self.predict(np.asarray(imgs))  # tf_aerial_images.py:266-267
+                if self._summary is not None:
+                    self._summary.add_to_training_summary(train_masks, labels, step)
+        if self._summary is not None:
+            self._flush_scalars()
+            self._summary.flush()
         self.last_epoch_stats = {"loss": None if last is None else float(last), "soft_errors": float(num_errors), "patches": total}
         return self.last_epoch_stats
 
@@ -191,11 +276,14 @@ class ConvolutionalModel:
         net.training = False
         reduced = False
         if os.environ.get("RSU_PREDICT_SHARED", "1") == "1" and pps > 1:
+            # every rank fills the tiles of its own phase classes (zeros elsewhere) and overlap-adds the lot locally: the hit counts are
+            # then complete on every rank, and ONE all-reduce of the accumulator (H*H floats per image variant, 1.4 MB at 604 px --
+            # not the 1.3 GB of tiles) completes the sums
             tiles = self._shared_window_tiles(imgs_t, pps)
-            if self.world > 1:
-                dist.all_reduce(tiles)   # every rank filled the tiles of its own phase classes, zeros elsewhere
             acc.add(tiles.view(-1, P, P), 0)
-            reduced = True   # (the tiles were exchanged before the overlap-add)
+            if self.world > 1:
+                dist.all_reduce(acc.acc)
+            reduced = True
         else:
             per = -(-num_patches // self.world)
             lo, hi = min(self.rank * per, num_patches), min((self.rank + 1) * per, num_patches)
@@ -292,7 +380,25 @@ class ConvolutionalModel:
             masks.append(self.predict(imgs[start:start + pred_batch_size]))
         return np.concatenate(masks, axis=0) if len(masks) > 1 else masks[0]
 
+    def quantize_mask(self, masks, threshold, patch_size):
+        """images.quantize_mask (images.py:256-266) on the device: masks [n, H, H, 1] float -> same shape, every patch_size block
+        overwritten with its label mean(mask >= 0.5) > threshold"""
+        import ctypes
+        a = np.asarray(masks)
+        t = torch.as_tensor(np.ascontiguousarray(a[..., 0], dtype=np.float32)).to(self.net.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.net.device).cuda_stream)
+        call("rsu_quantize_mask", ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t.data_ptr()), t.shape[0], t.shape[1], int(patch_size),
+             float(threshold), st)
+        return t.cpu().numpy()[..., None].astype(a.dtype)
+
     # ------------------------------------------------------------------ checkpoints
+    def save_as(self, path):
+        """tf_aerial_images.py:458: the saver writing to an explicit path"""
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in self.net.state_dict().items()})
+        return path
+
     def save(self, epoch=0):
         """tf_aerial_images.py:343-349: {save_path}/{experiment_name}/model-epoch-{epoch:03d}.chkpt(.npz) holding every variable
         under its TF name and layout, its Momentum slot and global_step."""
@@ -303,6 +409,31 @@ class ConvolutionalModel:
             np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in self.net.state_dict().items()})
             print("Model saved in file: {}".format(path))
         return path
+
+    def restore_from_tf_arrays(self, arrays):
+        """Load a checkpoint of the REFERENCE: `arrays` maps TensorFlow variable names to numpy arrays, as written by
+        tools/export_tf_checkpoint.py on a machine that has TensorFlow (tf.train.load_checkpoint(...).get_tensor(name) for every
+        name; tf_aerial_images.py:171 saves all global variables). Names and layouts are the reference's own, so this is a pure
+        rename: `<var>` -> weights, `<var>/Momentum` -> optimizer slots, `global_step` (tf_aerial_images.py:113) -> step counter.
+        A ':0' suffix and a leading scope are tolerated; missing variables raise KeyError."""
+        clean = {}
+        for k, v in arrays.items():
+            k = k[:-2] if k.endswith(":0") else k
+            clean[k] = np.asarray(v)
+        d = {}
+        for n in self.net.names:
+            hit = [k for k in clean if k == n or k.endswith("/" + n)]
+            if not hit:
+                raise KeyError("variable %r not found in the exported checkpoint" % n)
+            d[n] = clean[hit[0]]
+            if d[n].shape != tuple(self.net.w[n].shape):
+                raise ValueError("variable %r: checkpoint shape %s, network %s" % (n, d[n].shape, tuple(self.net.w[n].shape)))
+            mom = [k for k in clean if k == n + "/Momentum" or k.endswith("/" + n + "/Momentum")]
+            if mom:
+                d[n + "/Momentum"] = clean[mom[0]]
+        gs = [k for k in clean if k == "global_step" or k.endswith("/global_step")]
+        d["global_step"] = int(clean[gs[0]]) if gs else 0
+        self.net.load_state_dict(d)
 
     def restore(self, date=None, epoch=None, file=None):
         """Restores model from saved checkpoint (tf_aerial_images.py:351-379): explicit file, else newest experiment

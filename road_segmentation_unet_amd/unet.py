@@ -98,6 +98,8 @@ class UNet:
         self.B, self.P = batch_size, patch_size
         self.S = input_size_needed(patch_size, num_layers)
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)  # the library works on the HIP current device (rsu.h "devices")
         self.training = training
         self.keep = 1.0        # dropout keep probability of the forward pass in flight (set by forward_device)
         self.dropout_seed = int(seed) if seed is not None else 0

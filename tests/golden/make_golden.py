@@ -108,6 +108,23 @@ g7m = rng.rand(2, 40, 40).astype(np.float32)
 out["g7_in3"], out["g7_out3_off0"] = g7m, images.expand_and_rotate(g7m, [0, 30], 0)
 out["g7_scipy"] = np.array(scipy.__version__)
 
+# G10 post-processing images + the metrics' label patches (src/images.py:102-128,282-309; src/summary.py:134-139 with a stub tensorflow)
+g10i = rng.rand(2, 32, 32, 3)
+g10m = rng.rand(2, 32, 32, 1)
+out["g10_imgs"], out["g10_masks"] = g10i, g10m
+out["g10_overlays_f095"] = images.overlays(g10i, g10m)
+out["g10_overlays_f04"] = images.overlays(g10i, g10m, fade=0.4)
+g10p = (rng.rand(2, 32, 32) > 0.6) * 1
+g10t = (rng.rand(2, 32, 32) > 0.5) * 1.0
+out["g10_pred"], out["g10_true"] = g10p, g10t
+out["g10_overlap"] = images.overlap_pred_true(g10p, g10t)
+out["g10_error"] = images.overlapp_error(g10p, g10t)
+out["g10_u8"] = images.img_float_to_uint8(g10m)
+import summary  # noqa: E402  (reference module; tensorflow is the stub registered above)
+g10l = rng.rand(3, 48, 48) * 0.6
+out["g10_lab_in"] = g10l
+out["g10_label_patches"] = summary.Summary.img_to_label_patches(None, g10l.copy())
+
 # F: the 30 command-line flags (name, type, default) parsed from the reference's DEFINE_* calls -- data, not source
 import json  # noqa: E402
 import re  # noqa: E402

@@ -29,8 +29,9 @@ def test_cli_train_predict_submission(tmp_path):
             "--train_data_dir=%s" % tr, "--eval_data_dir=%s" % ev, "--save_path=%s" % save, "--pred_batch_size=2",
             "--rotation_angles=0,90", "--seed=5"]  # (like the reference, the training path needs the angles: None is not iterable there either)
     assert main(argv) == 0   # dropout stays at the flag default 0.8
-    runs = [d for d in os.listdir(save)]
+    runs = [d for d in os.listdir(save) if os.path.isdir(save / d)]
     assert len(runs) == 1
+    assert any(f.endswith("-model.chkpt.npz") for f in os.listdir(save))   # tf_aerial_images.py:458: the model used for the submission
     files = os.listdir(save / runs[0])
     assert any(f.endswith(".npz") for f in files), files
     csvs = [f for f in files if f.endswith(".csv")]

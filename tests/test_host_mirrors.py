@@ -68,3 +68,46 @@ def test_pixel_f1():
     # tp=4, fp=1, fn=4 -> precision 0.8, recall 0.5
     assert abs(pixel_f1(p, t) - 2 / (1 / 0.5 + 1 / 0.8)) < 1e-12
     assert pixel_f1(np.zeros_like(t), t) == 0.0
+
+
+def test_postprocessing_images_against_reference_goldens(golden):
+    """overlays / overlap_pred_true / overlapp_error / img_float_to_uint8 (images.py:19-21,102-128,282-309) and the label patches
+    the metrics are computed on (summary.py:134-139, the in-place resize quirk included)"""
+    np.testing.assert_array_equal(hostio.img_float_to_uint8(golden["g10_masks"]), golden["g10_u8"])
+    np.testing.assert_array_equal(hostio.overlays(golden["g10_imgs"], golden["g10_masks"]), golden["g10_overlays_f095"])
+    np.testing.assert_array_equal(hostio.overlays(golden["g10_imgs"], golden["g10_masks"], fade=0.4), golden["g10_overlays_f04"])
+    np.testing.assert_array_equal(hostio.overlap_pred_true(golden["g10_pred"], golden["g10_true"]), golden["g10_overlap"])
+    np.testing.assert_array_equal(hostio.overlapp_error(golden["g10_pred"], golden["g10_true"]), golden["g10_error"])
+    got = hostio.img_to_label_patches(golden["g10_lab_in"])
+    np.testing.assert_array_equal(got, golden["g10_label_patches"])
+    n = got.shape[0]
+    assert got.reshape(-1)[n:].sum() == 0  # the quirk: every real label sits in the first n entries, zeros behind
+
+
+def test_rsu_plan_matches_the_python_shape_table():
+    """rsu_plan (host arithmetic only, no GPU) against unet.param_shapes / input_size_needed and the buffer walk of UNet"""
+    import ctypes
+
+    from road_segmentation_unet_amd import _lib, unet
+    lib = _lib.lib()
+    for L, root, P, dil in [(3, 16, 188, 0), (5, 64, 388, 0), (6, 64, 388, 1), (4, 32, 92, 1)]:
+        n = ctypes.c_int(0)
+        tot = _lib.RsuPlanTotals()
+        assert lib.rsu_plan(L, root, P, dil, 4, None, 0, ctypes.byref(n), ctypes.byref(tot)) == 0
+        rows = (_lib.RsuPlanRow * n.value)()
+        assert lib.rsu_plan(L, root, P, dil, 4, rows, n.value, ctypes.byref(n), ctypes.byref(tot)) == 0
+        assert tot.input_size == unet.input_size_needed(P, L)
+        assert tot.num_params == sum(int(np.prod(s)) for _, s in unet.param_shapes(L, root, bool(dil)))
+        convs = [r for r in rows if r.kind == 1]
+        # every 3x3 kernel of the live graph appears once, with the reference's channel counts
+        want = [(s[2], s[3]) for nme, s in unet.param_shapes(L, root, bool(dil))
+                if nme.endswith("kernel") and len(s) == 4 and s[0] == 3 and not unet._is_dead(nme, L)]
+        assert sorted((r.Cin, r.Cout) for r in convs) == sorted(want)
+        assert rows[0].kind == 0 and rows[0].Hin == tot.input_size and rows[n.value - 1].kind == 4 and rows[n.value - 1].Hout == P
+        ups = [r for r in rows if r.kind == 3]
+        assert len(ups) == L - 1 and all(r.Hout == 2 * r.Hin and r.Cin == 2 * r.Cout for r in ups)
+        dec = [r for r in convs if r.nsrc > 1]
+        assert len(dec) == L - 1 and all(r.nsrc == (3 if dil else 2) for r in dec)
+        small = (_lib.RsuPlanRow * 2)()
+        assert lib.rsu_plan(L, root, P, dil, 4, small, 2, ctypes.byref(n), None) == -12  # RSU_ENOMEM, count still reported
+    assert lib.rsu_plan(5, 64, 390, 0, 4, None, 0, ctypes.byref(n), None) == -22  # the reference's input_size assertion
