@@ -64,6 +64,10 @@ int rsu_get_cu_budget(void);
  * tuned so far. */
 int rsu_set_autotune(int on);
 int rsu_autotune_entries(void);
+/* The table of measured choices as rows of 17 ints (opaque key words + choice): export after a run, import before another (a
+ * profiling run then issues no timing launches). export returns the number of entries (rows may be NULL to count). */
+int rsu_autotune_export(int* rows, int capacity);
+int rsu_autotune_import(const int* rows, int nrows);
 /* unet.py:100-115 input_size_needed(output_size, num_layers). RSU_EINVAL where the reference asserts. */
 int rsu_input_size_needed(int output_size, int num_layers, int* input_size);
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rsu_get_cu_budget": (_i, []),
     "rsu_set_autotune": (_i, [_i]),
     "rsu_autotune_entries": (_i, []),
+    "rsu_autotune_export": (_i, [_PI, _i]),
+    "rsu_autotune_import": (_i, [_PI, _i]),
     "rsu_input_size_needed": (_i, [_i, _i, _PI]),
     "rsu_packed_bytes": (_sz, [_i, _i, _PI, _i]),
     "rsu_pack_conv_fwd": (_i, [_vp, _vp, _i, _i, _i, _PI, _i, _vp]),

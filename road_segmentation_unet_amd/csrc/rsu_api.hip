@@ -66,6 +66,31 @@ extern "C" int rsu_autotune_entries(void) {
     return (int)g_tuned.size();
 }
 
+// the measured choices as rows of 17 ints (16 key words + the choice): a profile run imports the table a bench run exported, so that
+// its kernel statistics hold no timing launches
+extern "C" int rsu_autotune_export(int* rows, int capacity) {
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    int n = 0;
+    for (const auto& kv : g_tuned) {
+        if (rows && n < capacity) {
+            for (int i = 0; i < 16; ++i) rows[n * 17 + i] = kv.first[i];
+            rows[n * 17 + 16] = kv.second;
+        }
+        ++n;
+    }
+    return n;
+}
+extern "C" int rsu_autotune_import(const int* rows, int nrows) {
+    if (!rows || nrows < 0) return RSU_EINVAL;
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    for (int r = 0; r < nrows; ++r) {
+        std::array<int, 16> k;
+        for (int i = 0; i < 16; ++i) k[i] = rows[r * 17 + i];
+        g_tuned[k] = rows[r * 17 + 16];
+    }
+    return RSU_OK;
+}
+
 extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input_size) {
     // unet.py:100-115: (L-1) x { assert even; o = (o+4)/2 }, (L-1) x { o = (o+4)*2 }, +4
     if (!input_size || num_layers < 1 || output_size < 1) return RSU_EINVAL;

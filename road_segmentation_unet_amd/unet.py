@@ -493,7 +493,9 @@ class UNet:
                         call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
                              _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, self._stream())
             if i > 0:
-                first_name = ("conv_dilut_%d/atrous_conv1/kernel" if self.dilated else "conv_%d/conv1/kernel") % i
+                # first LIVE variable of the level in creation order: the dilated pair of level L-1 is dead and sits behind n_live
+                # (marking it ready launched nothing, and the largest block waited for level L-2)
+                first_name = ("conv_dilut_%d/atrous_conv1/kernel" if (self.dilated and i < L - 1) else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
         self._join_side()
         # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):

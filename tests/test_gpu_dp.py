@@ -79,7 +79,7 @@ def test_two_rank_step_equals_single_process_step():
         p.start()
     res = [q.get(timeout=300) for _ in range(2)]
     got = {r[0]: r[1] for r in res}
-    for r in res:   # inference: the phase classes of the shared-window sliding window are dealt over the ranks, tiles all-reduced
+    for r in res:   # inference: the phase classes of the shared-window sliding window are dealt over the ranks, the overlap accumulator all-reduced
         np.testing.assert_allclose(r[2], ref_masks, rtol=0, atol=1e-6)
     for p in procs:
         p.join(60)

@@ -92,37 +92,9 @@ def test_softmax_ce():
 
 
 def _torch_unet(params, X, L, root, dilated):
-    """the graph of the reference's unet.py:12-97 in stock torch ops, float64, NCHW"""
-    P = {k: t64(v).requires_grad_(True) for k, v in params.items()}
-
-    def conv(x, name, dil=1, relu=True, k=3):
-        w = P[name + "/kernel"].permute(3, 2, 0, 1)
-        y = F.conv2d(x, w, P[name + "/bias"], dilation=dil)
-        return F.relu(y) if relu else y
-
-    net = conv(nhwc_to_nchw(X) - 0.5, "color_space_adjust", relu=False)
-    skips = []
-    for i in range(L):
-        dil = None
-        if dilated:
-            dil = conv(conv(net, "conv_dilut_%d/atrous_conv1" % i, 2), "conv_dilut_%d/atrous_conv2" % i, 2)
-        net = conv(conv(net, "conv_%d/conv1" % i), "conv_%d/conv2" % i)
-        skips.append((net, dil))
-        net = F.max_pool2d(net, 2, 2)
-    net = skips.pop()[0]
-    for i in range(L - 1):
-        kt = P["up_conv_%d/kernel" % i].permute(3, 2, 0, 1)
-        net = F.conv_transpose2d(net, kt, P["up_conv_%d/bias" % i], stride=2)
-        s, d = skips.pop()
-        h, w = net.shape[2], net.shape[3]
-
-        def crop(t):
-            oy, ox = (t.shape[2] - h) // 2, (t.shape[3] - w) // 2
-            return t[:, :, oy:oy + h, ox:ox + w]
-        parts = [crop(s)] + ([crop(d)] if dilated else []) + [net]
-        net = torch.cat(parts, 1)
-        net = conv(conv(net, "conv_%d/conv1" % (L + i)), "conv_%d/conv2" % (L + i))
-    return conv(net, "weight_output", relu=False), P
+    """the graph of the reference's unet.py:12-97 in stock torch ops, float64, NCHW (oracle/torch_ref.py)"""
+    from oracle.torch_ref import torch_unet
+    return torch_unet(params, X, L, root, dilated, dtype=torch.float64)
 
 
 @pytest.mark.parametrize("L,root,P,dilated", [(2, 4, 12, False), (3, 4, 20, False), (3, 4, 20, True)])
