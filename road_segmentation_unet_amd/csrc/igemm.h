@@ -52,6 +52,7 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x
 // third generation (ping-pong wave groups; igemm_pp.hip): 3x3 taps, stride 1; tile shapes, LDS budget and results as igemm_fwd2
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
+bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
 
 // ---------------------------------------------------------------------------------------------
 // igemm_wgrad: slab[z][tap][cs_off+cs][cf] = sum_{pix in split z} S[n][pix*stride + tap*dil][cs] * F[n][pix][cf]

@@ -68,7 +68,7 @@ constexpr int pp_na_idx(int NAW, int g, int j) {  // index of the slot's first p
     return n;
 }
 }  // namespace
-template <int WCO, int WPX, int CT, int PT, int NAW, int WP0, bool STAMP>
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 igemm_pp_kernel(const IgFwdParams p) {
     constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
@@ -86,16 +86,24 @@ igemm_pp_kernel(const IgFwdParams p) {
     static_assert((CT % 2) == 0, "bad config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
-    const int ABUF = p.g.npix_max * 64;
-    const int a_base = NWB * WBUF;
-    const int dummy_base = a_base + NAB * ABUF;  // 1 KiB scratch slot for padding loads
+    // geometry is a compile-time constant of the instantiation (strip width 2^LSW, 3x3 taps, dilation 1, stride 1): halo addresses
+    // become immediate offsets of the LDS reads and most of the scalar arithmetic of an R interval disappears (an R-interval
+    // instruction costs ~6 cycles of a budget of ~290: probes/probe_mfma_rate.hip)
+    constexpr int SW = 1 << LSW, lsw = LSW, TR = TM >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8;              // halo row pitch in pixels (plan_geo_aligned)
+    constexpr int NPIX = ((TR + 2) * CW + 31) / 32 * 32;  // halo pixels per slot
+    constexpr int ABUF = NPIX * 64;
+    constexpr int ROWB = CW * 64;                         // one kernel row down in the halo tile
+    constexpr int a_base = 0;                             // LDS: [halo slot 0][halo slot 1][weight slots 0..2][scratch][bias]
+    constexpr int WBASE = NAB * ABUF;
+    constexpr int dummy_base = WBASE + NWB * WBUF;        // 1 KiB scratch slot for padding loads
+    static_assert(ABUF + 2 * ROWB < 65536, "halo offsets must fit the 16-bit offset field of ds_read");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, w4 = wave & 3;
     const int wco = wave / WPX, wpx = wave % WPX;
     const int g4 = lane >> 4, l15 = lane & 15;
-    const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TM >> lsw;
 
     // ---- this workgroup's tile list (XCD-aware numbering as in igemm_fwd2)
     int vid = blockIdx.x;
@@ -133,13 +141,12 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int hp0 = ty * CW + tx;
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
-            const int hp = hp0 + kx * p.dil;
+            const int hp = hp0 + kx;
             boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
         }
     }
-    const int afrag = (wco * CT * 64 + lane) * 16;  // this lane's 16 bytes inside weight tile 0 of the wave
-    const int row_bytes = (CW * p.dil) << 6;        // one kernel row down in the halo tile
-    const int npieces = p.g.npix_max >> 4;
+    const int afrag = WBASE + (wco * CT * 64 + lane) * 16;  // this lane's 16 bytes inside weight tile 0 of the wave (slot 0)
+    constexpr int npieces = NPIX >> 4;
     const int lq = lane >> 2;
     auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
 
@@ -164,7 +171,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         constexpr int G = decltype(gc_)::value;
         const __amdgpu_buffer_rsrc_t rw = mk(p.wp);
 #pragma unroll
-        for (int q = 0; q < (G ? WP1 : WP0); ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + slot * WBUF + (((G ? WP0 : 0) + q) * NG + w4) * 1024));
+        for (int q = 0; q < (G ? WP1 : WP0); ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + WBASE + slot * WBUF + (((G ? WP0 : 0) + q) * NG + w4) * 1024));
         if (++w_sit == nstage_tile) {
             w_sit = 0;
             w_soff = w_tile_soff;
@@ -208,7 +215,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         for (int q = 0; q < NAV; ++q) {
             const int hp = my_piece(q) * 16 + lq;
             const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
-            const int rr = div_magic(hp, p.g.inv_CW);
+            const int rr = hp / CW;   // compile-time divisor
             const int cc = hp - rr * CW;
             const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win) &&
                             (q < (grp ? pp_na_total(NAW, 1) : pp_na_total(NAW, 0)));
@@ -221,7 +228,7 @@ igemm_pp_kernel(const IgFwdParams p) {
     auto a_begin = [&]() {  // the next chunk of the stream: moves on to the next source / tile where one ends
         if (a_cl == 0) {
             if (a_started) {
-                ++pk;
+                if (pk + 1 < my_tiles) ++pk;  // behind the last tile the stream prefetches that tile again (valid memory, a slot nobody reads)
                 ptile = decode(pk);
                 a_si = 0;
                 a_next_src = p.nchunk[0];
@@ -363,7 +370,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         }
         // every mask / accumulate load of the tile is requested before the first is used: one memory latency per tile, in registers
         // the stage fragments no longer need (with both a mask and an accumulate source: two batches)
-        constexpr int EB = NST;
+        constexpr int EB = NST <= 8 ? NST : NST / 2;
 #pragma unroll
         for (int b0 = 0; b0 < NST; b0 += EB) {
             unsigned voffs[EB];
@@ -422,7 +429,7 @@ igemm_pp_kernel(const IgFwdParams p) {
     setup_a(ptile, 0);
     a_next_src = p.nchunk[0];
     a_begin();
-    if (!(p.dbg & 2)) {
+    if (!(DBG && (p.dbg & 2))) {
         if (grp) {
             a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
@@ -433,7 +440,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         }
     }
     a_end();
-    if (!(p.dbg & 1)) {
+    if (!(DBG && (p.dbg & 1))) {
         if (grp) {
             issue_w(std::integral_constant<int, 1>{}, 0);
             issue_w(std::integral_constant<int, 1>{}, 1);
@@ -451,32 +458,35 @@ igemm_pp_kernel(const IgFwdParams p) {
         clk0 = __builtin_amdgcn_s_memtime();
         rt0 = __builtin_amdgcn_s_memrealtime();
     }
-    int gc = 0;       // stream chunk counter
-    int ca_slot = 0;  // halo ring slot of the chunk being computed
-    for (int ck = 0; ck < my_tiles; ++ck) {
-        const Tile ctile = decode(ck);
-        // accumulators live for exactly one tile; they start at the bias
-        f32x4 acc[CT][PT];
+    // ---- the chunk stream, one copy of the loop per wave group (no group tests inside), two chunks per iteration (the halo slot of a
+    // chunk is its parity: every LDS address of an R interval is a per-lane constant plus an immediate). Accumulators live across
+    // the loop; a tile starts them at the bias and ends with its epilogue, which opens the wave's next R interval.
+    f32x4 acc[CT][PT];
+    auto run_stream = [&](auto gconst) {
+        constexpr int G = decltype(gconst)::value;
+        int c = 0;               // chunk inside the current tile
+        int ck = 0;              // current tile
+        Tile ctile = decode(0);
+        auto chunk = [&](auto parc, int gc) {
+            constexpr int PAR = decltype(parc)::value;
+            if (c == 0) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
-                                                                                 ((wco * (CT / 2) + (ct >> 1)) * 32 + 8 * g4 + (ct & 1) * 4) * 4);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
+                                                                                         ((wco * (CT / 2) + (ct >> 1)) * 32 + 8 * g4 + (ct & 1) * 4) * 4);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                acc[ct][pt] = bv;
-                asm volatile("" : "+v"(acc[ct][pt]));
+                    for (int pt = 0; pt < PT; ++pt) {
+                        acc[ct][pt] = bv;
+                        asm volatile("" : "+v"(acc[ct][pt]));
+                    }
+                }
             }
-        }
-        for (int c = 0; c < nchunks; ++c, ++gc) {
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
-            const bool steady = gc + 1 < GC;            // a next chunk exists: its halo is prefetched and the counted waits apply
-            const int ab = a_base + ca_slot * ABUF;
             auto phase = [&](auto jc) {
                 constexpr int J = decltype(jc)::value;
                 // ================= R interval: the stage's fragment reads + bookkeeping for the stages ahead
                 bf16x8 fa[TPS][CT], fb[TPS][PT];
-                if (!(p.dbg & 32)) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
-                    const int rowoff = ab + J * row_bytes;  // wave-uniform
+                if (!(DBG && (p.dbg & 32))) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
 #pragma unroll
                     for (int tl = 0; tl < TPS; ++tl) {
 #pragma unroll
@@ -484,34 +494,27 @@ igemm_pp_kernel(const IgFwdParams p) {
                             fa[tl][ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + afrag + J * WBUF + (tl * WT + ct) * 1024);
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt)
-                            fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + (boff[pt][tl] + rowoff));
+                            fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + boff[pt][tl] + (a_base + PAR * ABUF + J * ROWB));
                     }
                 }
                 // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
-                if (grp) {
-                    if constexpr (pp_na(NAW, 1, J) > 0 || J == 0) {
-                        if (steady && !(p.dbg & 2)) {
-                            if constexpr (J == 0) a_begin();
-                            a_pieces(std::integral_constant<int, 1>{}, jc);
-                        }
+                if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
+                    if (!(DBG && (p.dbg & 2))) {
+                        if constexpr (J == 0) a_begin();
+                        a_pieces(gconst, jc);
                     }
-                    if constexpr (J == 2) { if (steady) a_end(); }
-                    if (!(p.dbg & 1)) issue_w(std::integral_constant<int, 1>{}, (J + 2) % NWB);
+                }
+                if constexpr (J == 2) a_end();
+                if constexpr ((G ? WP1 : WP0) > 0) {
+                    if (!(DBG && (p.dbg & 1))) issue_w(gconst, (J + 2) % NWB);
+                }
+                if constexpr (G == 1) {
                     // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
-                    if (!steady) {
-                        RSU_WAIT_VMCNT(0);
-                    } else if (J == 0 && after_epi) {
+                    if (J == 0 && after_epi) {
                         RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
                     } else {
                         RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
                     }
-                } else {
-                    if (steady && !(p.dbg & 2)) {
-                        if constexpr (J == 0) a_begin();
-                        a_pieces(std::integral_constant<int, 0>{}, jc);
-                    }
-                    if constexpr (J == 2) { if (steady) a_end(); }
-                    if (!(p.dbg & 1)) issue_w(std::integral_constant<int, 0>{}, (J + 2) % NWB);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
                 stamp();
@@ -520,7 +523,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                 // ================= M interval: the MFMAs of this stage, nothing else
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
-                if (!(p.dbg & 32))
+                if (!(DBG && (p.dbg & 32)))
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl)
 #pragma unroll
@@ -529,10 +532,8 @@ igemm_pp_kernel(const IgFwdParams p) {
                         for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[tl][ct], fb[tl][pt]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!grp) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
-                    if (!steady) {
-                        RSU_WAIT_VMCNT(0);
-                    } else if (J == 0 && after_epi) {
+                if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
+                    if (J == 0 && after_epi) {
                         RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
                     } else if (J == 2) {
                         RSU_WAIT_VMCNT(WP0);
@@ -548,11 +549,23 @@ igemm_pp_kernel(const IgFwdParams p) {
             phase(std::integral_constant<int, 0>{});
             phase(std::integral_constant<int, 1>{});
             phase(std::integral_constant<int, 2>{});
-            ca_slot ^= 1;
+            if (c == nchunks - 1) {
+                // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
+                if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
+                c = 0;
+                ++ck;
+                if (ck < my_tiles) ctile = decode(ck);
+            } else {
+                ++c;
+            }
+        };
+        for (int gc = 0; gc < GC; gc += 2) {
+            chunk(std::integral_constant<int, 0>{}, gc);
+            if (gc + 1 >= GC) break;
+            chunk(std::integral_constant<int, 1>{}, gc + 1);
         }
-        // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
-        if (!(p.dbg & 8)) epilogue(ctile, acc);
-    }
+    };
+    if (grp) run_stream(std::integral_constant<int, 1>{}); else run_stream(std::integral_constant<int, 0>{});
     if (!grp) bar();  // G0 sits out the last interval (G1's last epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in this workgroup's LDS after it has gone
     if constexpr (STAMP) {
@@ -577,18 +590,11 @@ template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX =
 template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
 template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
 template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NAS = PP_NAS(0, 3, 3, 2, 2), WP0 = 0; };
-// (the five-fragment shapes 128x320 / 64x640 do not fit: three taps of fragments beside 80 accumulators spill; igemm_fwd2 runs them)
-// experimental distributions of the 128x256 shape (RSU_PP_VAR = 1..5, developer A/B)
-template <int V> struct PpVar;
-template <> struct PpVar<1> { static constexpr int NAS = PP_NAS(2, 2, 2, 1, 1), WP0 = 3; };
-template <> struct PpVar<2> { static constexpr int NAS = PP_NAS(0, 0, 4, 0, 4), WP0 = 0; };
-template <> struct PpVar<3> { static constexpr int NAS = PP_NAS(3, 0, 3, 0, 2), WP0 = 0; };
-template <> struct PpVar<4> { static constexpr int NAS = PP_NAS(0, 0, 4, 0, 4), WP0 = 2; };
-template <> struct PpVar<5> { static constexpr int NAS = PP_NAS(0, 0, 8, 0, 0), WP0 = 0; };
-
-template <int WCO, int WPX, int CT, int PT, int NAS, int WP0, bool STAMP>
-static hipError_t pp_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
-    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, NAS, WP0, STAMP>;
+// (128x320 / 64x640, five pixel fragments per wave: measured 20-40 % slower than igemm_fwd2's -- three taps of fragments beside 80
+// accumulators leave no registers for the tile bookkeeping; not instantiated)
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG>
+static hipError_t pp_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG>;
     const size_t lds = igemm_fwd2_lds_bytes(cfg, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -599,16 +605,55 @@ static hipError_t pp_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStr
     hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(512), lds, st, p);
     return hipGetLastError();
 }
-template <int CFG, bool STAMP = false>
+// strip widths an instantiation exists for: the halo tile must fit the DMA pieces of a chunk and the 16-bit offsets of the LDS reads
+constexpr bool pp_geo_ok(int TM, int LSW, int NAS) {
+    const int SW = 1 << LSW, TR = TM >> LSW;
+    if (TR < 1 || TR * SW != TM) return false;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    int pieces = 0;
+    for (int k = 0; k < 5; ++k) pieces += pp_na_slot(NAS, k);
+    return NPIX <= pieces * 4 * 16 && NPIX * 64 + 2 * CW * 64 < 65536;
+}
+// the kernel is instantiated per strip width (2^LSW = 8 .. 64): the planner's geometry must be the one the instantiation assumes
+template <int WCO, int WPX, int CT, int PT, int NAS, int WP0, bool STAMP, bool DBG = false>
+static hipError_t pp_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    constexpr int TM = WPX * PT * 16;
+    const int SW = 1 << p.lsw, TR = TM >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    if (p.dil != 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX || TR < 1) return hipErrorInvalidValue;
+    switch (p.lsw) {
+        case 3: if constexpr (pp_geo_ok(TM, 3, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 3, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 4: if constexpr (pp_geo_ok(TM, 4, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 4, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 5: if constexpr (pp_geo_ok(TM, 5, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 5, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 6: if constexpr (pp_geo_ok(TM, 6, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 6, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+    }
+    return hipErrorInvalidValue;
+}
+template <int CFG, bool STAMP = false, bool DBG = false>
 static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
     using C = PpCfg<CFG>;
-    return pp_launch_kernel<C::WCO, C::WPX, C::CT, C::PT, C::NAS, C::WP0, STAMP>(CFG, p, gx, st);
+    return pp_launch_kernel<C::WCO, C::WPX, C::CT, C::PT, C::NAS, C::WP0, STAMP, DBG>(CFG, p, gx, st);
 }
-template <int V>
-static hipError_t pp_launch_var(const IgFwdParams& p, int gx, hipStream_t st) {
-    return pp_launch_kernel<2, 4, 4, 4, PpVar<V>::NAS, PpVar<V>::WP0, false>(IGF2_CFG_128x256, p, gx, st);
+// (the five-fragment shapes are instantiated but lose: three taps of fragments beside 80 accumulators leave no room for the tile
+// bookkeeping, whose spills cost more than the lean loop gains; igemm_fwd2 keeps them)
+bool igemm_pp_has(int cfg) { return cfg >= 0 && cfg < IGF2_NCFG && cfg != IGF2_CFG_128x320 && cfg != IGF2_CFG_64x640; }
+// this launch, planned with this geometry, is one the ping-pong kernels are instantiated for (3x3 taps, stride 1, dilation 1, the
+// planner's halo tile for strip width 2^lsw)
+bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
+    if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
+    const int TM = igemm_fwd2_cfg_info(cfg).TM;
+    const int SW = 1 << p.lsw, TR = TM >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    if (TR < 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX) return false;
+    int nas = 0;
+    switch (cfg) {
+#define PP_CASE(C) case C: nas = PpCfg<C>::NAS; break;
+        PP_CASE(IGF2_CFG_128x256) PP_CASE(IGF2_CFG_64x512) PP_CASE(IGF2_CFG_128x128) PP_CASE(IGF2_CFG_64x256)
+        PP_CASE(IGF2_CFG_128x192) PP_CASE(IGF2_CFG_64x384)
+#undef PP_CASE
+    }
+    return pp_geo_ok(TM, p.lsw, nas);
 }
-bool igemm_pp_has(int cfg) { return cfg != IGF2_CFG_128x320 && cfg != IGF2_CFG_64x640; }
 // 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
@@ -616,14 +661,9 @@ hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, true>(p, gx, st);
         if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, true>(p, gx, st);
     }
-    if (cfg == IGF2_CFG_128x256 && (p.dbg >> 8)) {
-        switch (p.dbg >> 8) {
-            case 1: return pp_launch_var<1>(p, gx, st);
-            case 2: return pp_launch_var<2>(p, gx, st);
-            case 3: return pp_launch_var<3>(p, gx, st);
-            case 4: return pp_launch_var<4>(p, gx, st);
-            case 5: return pp_launch_var<5>(p, gx, st);
-        }
+    if (p.dbg & 63) {  // timing experiments (RSU_FWD_DBG bits 0-5): the build that tests those bits
+        if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, false, true>(p, gx, st);
+        if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, false, true>(p, gx, st);
     }
     switch (cfg) {
         case IGF2_CFG_128x256: return pp_launch_one<IGF2_CFG_128x256>(p, gx, st);

@@ -354,7 +354,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 // persistent conv launch of the chosen generation: the ping-pong kernel (igemm_pp.hip) runs the 3x3 stride-1 launches unless
 // RSU_FWD_GEN=2 asks for igemm_fwd2 (same tile shapes, same bits)
 static hipError_t launch_persistent(bool pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
-    if (pp && igemm_pp_has(cfg)) return igemm_pp_launch(cfg, p, gx, st);
+    if (pp && igemm_pp_supports(cfg, p)) return igemm_pp_launch(cfg, p, gx, st);
     return igemm_fwd2_launch(cfg, ntap, p, gx, gy, st);
 }
 
@@ -369,7 +369,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     if (out_bytes >= 0x7ffffff0L) return RSU_EINVAL;
     // RSU_FWD_GEN: 2 = igemm_fwd2 only; 3 (default) = the ping-pong kernel where it measured (or, untuned, is expected to be) faster;
     // 4 = the ping-pong kernel wherever it is built (tests)
-    const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1;
+    const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1 && dil == 1;
     for (int i = 0; i < nsrc; ++i)
         if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) return RSU_EINVAL;
     Fwd2Plan pl2;
@@ -426,10 +426,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.oH = oH; p.oW = oW; p.ostride = ostride;
     p.relu = relu; p.accumulate = accumulate;
     {
-        // untuned choice of the kernel generation: the ping-pong kernel on the 128-channel shapes (measured +5-10 % there; the
-        // 64-channel shapes keep more halo offsets per wave than their registers hold)
-        const bool pp = pp_ok && igemm_pp_has(pl2.cfg) &&
-                        (gen >= 4 || (tuned_pp >= 0 ? tuned_pp != 0 : igemm_fwd2_cfg_info(pl2.cfg).TN >= 128));
+        // kernel generation: the ping-pong kernel wherever it is instantiated (measured 10-20 % faster than igemm_fwd2 at every
+        // shape; launch_persistent falls back to igemm_fwd2 for the rest) unless the tuner measured otherwise for this geometry
+        const bool pp = pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0);
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
@@ -475,8 +474,8 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
                 for (int vpp = 0; vpp < 2; ++vpp) {  // both kernel generations of the shape
-                    if (vpp && !(pp_ok && igemm_pp_has(cfg))) continue;
-                    if (!vpp && gen >= 4 && pp_ok && igemm_pp_has(cfg)) continue;
+                    if (vpp && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
+                    if (!vpp && gen >= 4 && pp_ok && igemm_pp_supports(cfg, pt)) continue;
                     float ms_min = 1e30f;
                     for (int rep = 0; rep < 6; ++rep) {
                         HIP_CHECK_RET(hipEventRecord(e0, st));
