@@ -159,6 +159,17 @@ int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, cons
 int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate,
                         int N, int H, int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil,
                         rsu_stream_t stream);
+/* 1-bit ReLU masks (new; TensorFlow keeps the whole activation for ReluGrad). The forward conv can emit, beside y, one bit per element
+ * (y > 0): relu_bits uint8 [N][Ho][Wo][Cout/8], bit k of byte j = channel 8j+k (rsu_relu_bits_bytes bytes, < 128 MiB). Backward-data
+ * of the NEXT conv then takes these bits as its ReluGrad mask instead of re-reading the bf16 activation (16x fewer bytes):
+ * rsu_conv2d_bwd_data_bits == rsu_conv2d_bwd_data(relu_src = y, accumulate = 0, ci_off = 0, ci_cnt = Cin_total), bit for bit. */
+size_t rsu_relu_bits_bytes(int N, int H, int W, int C);
+int rsu_conv2d_fwd_bits(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* relu_bits, int N,
+                        int Hin, int Win, int Cout, int dil, rsu_stream_t stream);
+int rsu_conv_first_fwd_bits(const void* in16, const void* packed, const float* b, void* y, void* relu_bits, int N, int H, int W,
+                            int Cout, int dil, rsu_stream_t stream);
+int rsu_conv2d_bwd_data_bits(const void* dz, const void* packed_bwd, void* dx, const void* relu_bits, int N, int H, int W,
+                             int Cin_total, int Cout, int dil, rsu_stream_t stream);
 /* Conv2DBackpropFilter for the input channels held by `src` (rows [ci_off, ci_off+src.C) of dw):
  * dw f32 HWIO [3][3][Cin_total][Cout] (only those rows are written). (Ho, Wo) = size of dz.
  * ws: rsu_conv2d_bwd_weight_ws_floats() floats of scratch (split-K slabs). */

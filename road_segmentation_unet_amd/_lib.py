@@ -62,6 +62,10 @@ SIGNATURES = {
     "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_relu_bits_bytes": (_sz, [_i, _i, _i, _i]),
+    "rsu_conv2d_fwd_bits": (_i, [_PS, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_first_fwd_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_data_bits": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),

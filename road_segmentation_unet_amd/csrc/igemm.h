@@ -26,6 +26,9 @@ struct IgFwdParams {
     const float* bias;    // [Cout] or null
     bf16_t* out;          // [N][oH][oW][outC]
     const bf16_t* mask_src;  // same geometry as out, or null
+    unsigned char* bits_out;       // forward with ReLU: 1-bit "> 0" mask of out, [N][oH][oW][outC/8] bytes, or null
+    const unsigned char* bits_in;  // backward-data: that mask instead of mask_src (never both), or null
+    unsigned bits_bytes;           // size of the mask tensor (range check of the byte accesses; < 2^27)
     const void* zero_page;   // >= 64 zero bytes
     int N, Hin, Win;      // logical input window
     int Ho, Wo;           // output pixel grid of the GEMM (before output scatter)

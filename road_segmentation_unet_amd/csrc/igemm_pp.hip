@@ -337,13 +337,21 @@ igemm_pp_kernel(const IgFwdParams p) {
             asm volatile("" : "+v"(ones_pk));
             u32x4 mk4[NST];
             unsigned voffs[NST];
-            if (p.mask_src || !inside) {
+            unsigned mbits[NST];
+            const bool anybits = p.bits_out || p.bits_in;
+            const __amdgpu_buffer_rsrc_t brsrc =
+                __builtin_amdgcn_make_buffer_rsrc(p.bits_out ? (void*)p.bits_out : (void*)p.bits_in, 0, anybits ? (int)p.bits_bytes : 0, 0x00020000);
+            if (p.mask_src || !inside || anybits) {
 #pragma unroll
                 for (int e = 0; e < NST; ++e) voffs[e] = inside ? ovoff[e / (CT / 2)] + (e % (CT / 2)) * 64 : out_voff(T, e);
             }
             if (p.mask_src) {  // every mask load of the tile is in flight before the first is used (the stage fragments are dead by now)
 #pragma unroll
                 for (int e = 0; e < NST; ++e) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
+            }
+            if (p.bits_in) {  // 1-bit masks: one byte per store (a rejected lane's offset 0x80000000 >> 4 lies beyond bits_bytes: zeros)
+#pragma unroll
+                for (int e = 0; e < NST; ++e) mbits[e] = __builtin_amdgcn_raw_buffer_load_b8(brsrc, voffs[e] >> 4, sbase >> 4, 0);
             }
 #pragma unroll
             for (int e = 0; e < NST; ++e) {
@@ -360,7 +368,12 @@ igemm_pp_kernel(const IgFwdParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
                 }
-                if (p.mask_src || !inside) {
+                if (p.bits_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] &= relu_mask_from_bits(mbits[e], i);
+                }
+                if (p.bits_out) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)relu_bits_pk(r, ones_pk), brsrc, voffs[e] >> 4, sbase >> 4, 0);
+                if (p.mask_src || !inside || anybits) {
                     PP_STORE(r, voffs[e]);
                 } else {
                     if (pp == 0) PP_STORE(r, ovoff[pt]); else PP_STORE64(r, ovoff[pt]);
@@ -511,7 +524,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                 if constexpr (G == 1) {
                     // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
                     if (J == 0 && after_epi) {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
+                        if (p.bits_out) RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + 2 * NST); else RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
                     } else {
                         RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
                     }
@@ -534,7 +547,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
                     if (J == 0 && after_epi) {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
+                        if (p.bits_out) RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + 2 * NST); else RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
                     } else if (J == 2) {
                         RSU_WAIT_VMCNT(WP0);
                     } else {

@@ -360,7 +360,8 @@ static hipError_t launch_persistent(bool pp, int cfg, int ntap, const IgFwdParam
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
-                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st) {
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st,
+                   void* bits_out = nullptr, const void* bits_in = nullptr) {
     const int kh = ntap / kw;
     const long out_bytes = (long)N * oH * oW * outC * 2;
     const int gen = env_int("RSU_FWD_GEN", 3);
@@ -379,7 +380,13 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     const bool shared_chip = pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0;
     // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
     const bool tunable = env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
-    std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc, (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0),
+    // 1-bit ReLU masks (rsu_conv2d_fwd_bits / rsu_conv2d_bwd_data_bits): [N][oH][oW][outC/8] bytes, addressed at (bf16 byte offset) / 16
+    const long bits_bytes = (long)N * oH * oW * (outC / 8);
+    if ((bits_out || bits_in) && (ntap != 9 || ostride != 1 || outC != Cout || accumulate || (bits_in && mask_src) || (bits_out && !relu) ||
+                                  bits_bytes >= (1L << 27)))
+        return RSU_EINVAL;
+    std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
+                                (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (bits_out ? 8 : 0) | (bits_in ? 16 : 0),
                                 ostride, g_cu_budget.load() * 4 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
     bool tune_now = false;
@@ -418,6 +425,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.bias = bias;
     p.out = (bf16_t*)out;
     p.mask_src = (const bf16_t*)mask_src;
+    p.bits_out = (unsigned char*)bits_out;
+    p.bits_in = (const unsigned char*)bits_in;
+    p.bits_bytes = (unsigned)bits_bytes;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
@@ -515,6 +525,35 @@ extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packe
     if (Ho < 1 || Wo < 2) return RSU_EINVAL;
     return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
                    Ho, Wo, 1, 1, relu, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t rsu_relu_bits_bytes(int N, int H, int W, int C) { return (size_t)N * H * W * (C / 8); }
+extern "C" int rsu_conv2d_fwd_bits(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* relu_bits, int N,
+                                   int Hin, int Win, int Cout, int dil, rsu_stream_t stream) {
+    if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !relu_bits || Cout % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    const int Ho = Hin - 2 * dil, Wo = Win - 2 * dil;
+    if (Ho < 1 || Wo < 2) return RSU_EINVAL;
+    return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
+                   Ho, Wo, 1, 1, 1, 0, (hipStream_t)stream, relu_bits, nullptr);
+}
+extern "C" int rsu_conv_first_fwd_bits(const void* in16, const void* packed, const float* b, void* y, void* relu_bits, int N, int H, int W,
+                                       int Cout, int dil, rsu_stream_t stream) {
+    if (!in16 || !packed || !y || !relu_bits || Cout % 8 || H <= 2 * dil || W <= 2 * dil + 1 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
+    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    return run_fwd(&s, 1, packed, 0, rup(Cout, 128) / 16, 0, b, y, nullptr, N, H, W, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0, Ho, Wo, 1, 1, 1, 0,
+                   (hipStream_t)stream, relu_bits, nullptr);
+}
+extern "C" int rsu_conv2d_bwd_data_bits(const void* dz, const void* packed_bwd, void* dx, const void* relu_bits, int N, int H, int W,
+                                        int Cin_total, int Cout, int dil, rsu_stream_t stream) {
+    if (!dz || !packed_bwd || !dx || !relu_bits || Cout % 8 || Cin_total % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    const int Hd = H - 2 * dil, Wd = W - 2 * dil;  // dz size
+    if (Hd < 1 || Wd < 1 || W < 2) return RSU_EINVAL;
+    rsu_src_t s;
+    s.ptr = dz; s.H = Hd; s.W = Wd; s.C = Cout; s.oy = 0; s.ox = 0;
+    return run_fwd(&s, 1, packed_bwd, 0, rup(Cin_total, 128) / 16, 0, nullptr, dx, nullptr, N, Hd, Wd, H, W, Cin_total, Cin_total, 9, 3, dil,
+                   1, 2 * dil, H, W, 1, 1, 0, 0, (hipStream_t)stream, nullptr, relu_bits);
 }
 
 extern "C" size_t rsu_packed_first_bytes(int Cout) {

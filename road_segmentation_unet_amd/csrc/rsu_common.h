@@ -38,6 +38,24 @@ __device__ __forceinline__ unsigned pos_mask_pk_bf16(unsigned m, unsigned ones_p
     return t;
 }
 
+// ---- 1-bit ReLU masks. A lane's 16-byte store holds 8 consecutive channels of one pixel as 4 packed dwords (dword i = channels 2i
+// in the low, 2i+1 in the high half): their "> 0" flags are ONE byte of the mask tensor [pixel][C/8] (bit k = channel 8*byte + k),
+// at byte offset (bf16 byte offset) / 16. relu_bits_pk: the byte of a post-ReLU result (values >= 0: > 0 <=> != 0).
+__device__ __forceinline__ unsigned relu_bits_pk(const u32x4& r, unsigned ones_pk /* 0x00010001 in a VGPR */) {
+    unsigned t0, t1, t2, t3;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(r[0]), "v"(ones_pk));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(r[1]), "v"(ones_pk));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(r[2]), "v"(ones_pk));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(r[3]), "v"(ones_pk));
+    const unsigned a = t0 | (t1 << 2) | (t2 << 4) | (t3 << 6);  // low-half flags at bits 0,2,4,6, high-half flags at 16,18,20,22
+    return (a | (a >> 15)) & 0xffu;
+}
+// ... and back: bits 2i, 2i+1 of the byte as a packed 0 / 0xffff mask for dword i
+__device__ __forceinline__ unsigned relu_mask_from_bits(unsigned b, int i) {
+    const unsigned z = __builtin_amdgcn_ubfe(b, 2 * i, 1) | (__builtin_amdgcn_ubfe(b, 2 * i + 1, 1) << 16);
+    return __umul24(z, 0xffffu);
+}
+
 // ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand): no register is freed by
 // an MFMA, so the compiler cannot rename an accumulator and re-use its old registers while the matrix pipe still reads them.
 // The asm is opaque to hipcc's hazard recogniser, so the CALLER owns the wait states around it (DESIGN.md section 4;

@@ -106,6 +106,7 @@ class UNet:
         self.wstream = None    # second stream for the weight-gradient launches (see _Side)
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             self.wstream = torch.cuda.Stream(device=self.device)
+        self.bits, self._bits_of = {}, {}
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
@@ -217,6 +218,16 @@ class UNet:
                 if n.startswith("up_conv") and n.endswith("kernel"):
                     ws.append(lib.rsu_convT2x2_bwd_weight_ws_floats(s[3], s[2]))
             self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
+            # 1-bit ReLU masks of the conv1 / atrous_conv1 outputs (the ReluGrad masks of the conv2 backward-data launches): written by
+            # the forward conv beside its activation, read instead of it in backward (16x fewer bytes). Built and tested, but OFF by default (RSU_RELU_BITS=1 turns it on): measured -0.8 % on the step -- what the bf16 mask costs backward-data is one exposed round trip per tile, not its bytes, and the forward epilogue pays for building the bits.
+            self.bits = {}
+            if os.environ.get("RSU_RELU_BITS", "0") == "1":
+                for k, t in self.act.items():
+                    if k.startswith("c1_") or k.startswith("d1_"):
+                        nb = lib.rsu_relu_bits_bytes(t.shape[0], t.shape[1], t.shape[2], t.shape[3])
+                        if nb < (1 << 27):
+                            self.bits[k] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            self._bits_of = {self.act[k].data_ptr(): b for k, b in self.bits.items()}
             self.gfirst = torch.zeros((2, 9, 12, self.root), dtype=torch.float32, device=dev)  # gx of conv1 / atrous_conv1 (rsu.h)
 
     def _conv_sources_c(self, name, shape):
@@ -327,9 +338,24 @@ class UNet:
         cout = out.shape[3]
         cin = sum(s.C for s in srcs)
         ho = hin - 2 * dil
+        bits = self._bits_of.get(out.data_ptr()) if self.training else None
+        if bits is not None:  # the activation doubles as a ReluGrad mask in backward: emit its 1-bit form as well
+            self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd_bits", arr, len(srcs),
+                        _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), _ptr(bits), self.B, hin, hin, cout, dil,
+                        self._stream())
+            return
         self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd", arr, len(srcs),
                     _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
                     self._stream())
+
+    def _conv_first(self, name, out, h, dil, st):
+        bits = self._bits_of.get(out.data_ptr()) if self.training else None
+        if bits is not None:
+            call("rsu_conv_first_fwd_bits", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
+                 _ptr(bits), self.B, h, h, self.root, dil, st)
+        else:
+            call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
+                 self.B, h, h, self.root, dil, st)
 
     def dropout_key(self, site):
         """32-bit key of dropout site `site` (encoder level i -> i, decoder stage i -> L + i: the 2L-1 tf.nn.dropout calls of
@@ -352,14 +378,12 @@ class UNet:
                 # stream beside the main block (joined in front of the decoder)
                 with UNet._Side(self):
                     if i == 0:
-                        call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_dilut_0/atrous_conv1/kernel", "fwd"]),
-                             _ptr(self.w["conv_dilut_0/atrous_conv1/bias"]), _ptr(a["d1_0"]), B, h, h, self.root, 2, self._stream())
+                        self._conv_first("conv_dilut_0/atrous_conv1", a["d1_0"], h, 2, self._stream())
                     else:
                         self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
                     self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
             if i == 0:
-                call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk["conv_0/conv1/kernel", "fwd"]), _ptr(self.w["conv_0/conv1/bias"]),
-                     _ptr(a["c1_0"]), B, h, h, self.root, 1, st)
+                self._conv_first("conv_0/conv1", a["c1_0"], h, 1, st)
             else:
                 self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i])
             self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
@@ -414,6 +438,11 @@ class UNet:
         cout = self.w[name + "/kernel"].shape[3]
         cnt = dx.shape[3]
         ho = hin - 2 * dil
+        bits = self._bits_of.get(relu_src.data_ptr()) if relu_src is not None else None
+        if bits is not None and not accumulate and src_index == 0 and cnt == self.w[name + "/kernel"].shape[2]:
+            self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data_bits", _ptr(dz),
+                        _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(bits), self.B, hin, hin, cnt, cout, dil, self._stream())
+            return
         self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data", _ptr(dz),
                     _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
                     cout, dil, self._stream())

@@ -387,3 +387,46 @@ def test_abi_rejects_bad_geometry():
     o = ctypes.c_int()
     assert lib().rsu_input_size_needed(128, 5, ctypes.byref(o)) == -22
     assert lib().rsu_extract_tiles(None, None, 1, 20, 12, 8, 5, 0, 1, None) == -22
+
+
+@pytest.mark.parametrize("gen", [2, 4])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(2, 45, 52, 64, 96, 1), (1, 70, 66, 32, 128, 1), (1, 40, 40, 64, 64, 2)])
+def test_one_bit_relu_masks(gen, N, H, W, Cin, Cout, dil):
+    """rsu_conv2d_fwd_bits emits (y > 0) as one bit per element beside y; rsu_conv2d_bwd_data_bits with those bits equals
+    rsu_conv2d_bwd_data with the bf16 activation as relu_src, bit for bit (both conv generations; dilated convs run igemm_fwd2)"""
+    import os
+    old = os.environ.get("RSU_FWD_GEN")
+    os.environ["RSU_FWD_GEN"] = str(gen)
+    try:
+        rng = np.random.RandomState(N + H + Cout + dil)
+        x = hu.q(rng.standard_normal((N, H, W, Cin)).astype(np.float32))
+        w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+        b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+        xd, wp, bd = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b)
+        Ho, Wo = H - 2 * dil, W - 2 * dil
+        s = (RsuSrc * 1)(hu.src_of(xd, H, W))
+        y0 = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        y1 = torch.full_like(y0, float("nan"))
+        nb = lib().rsu_relu_bits_bytes(N, Ho, Wo, Cout)
+        bits = torch.full((nb,), 0xAA, dtype=torch.uint8, device=hu.DEV)
+        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y0), N, H, W, Cout, dil, 1, hu.stream())
+        call("rsu_conv2d_fwd_bits", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y1), hu.ptr(bits), N, H, W, Cout, dil, hu.stream())
+        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+        want = np.packbits((hu.host(y1) > 0).reshape(N, Ho, Wo, Cout // 8, 8), axis=-1, bitorder="little").reshape(-1)
+        np.testing.assert_array_equal(bits.cpu().numpy(), want)
+        # the next layer's backward-data: dz over the conv output (Cout2 channels) -> gradient of y, masked by (y > 0)
+        Cout2 = 64
+        w2 = (rng.standard_normal((3, 3, Cout, Cout2)) / np.sqrt(9 * Cout)).astype(np.float32)
+        dz = hu.dev_bf16(hu.q((rng.standard_normal((N, Ho - 2 * dil, Wo - 2 * dil, Cout2)) * 0.1).astype(np.float32)))
+        wb = hu.pack_conv_bwd(w2, 0, Cout)
+        d0 = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        d1 = torch.full_like(d0, float("nan"))
+        call("rsu_conv2d_bwd_data", hu.ptr(dz), hu.ptr(wb), hu.ptr(d0), hu.ptr(y1), 0, N, Ho, Wo, Cout, 0, Cout, Cout2, dil, hu.stream())
+        call("rsu_conv2d_bwd_data_bits", hu.ptr(dz), hu.ptr(wb), hu.ptr(d1), hu.ptr(bits), N, Ho, Wo, Cout, Cout2, dil, hu.stream())
+        assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+        assert float((hu.host(d1) != 0).mean()) > 0.2
+    finally:
+        if old is None:
+            os.environ.pop("RSU_FWD_GEN", None)
+        else:
+            os.environ["RSU_FWD_GEN"] = old
