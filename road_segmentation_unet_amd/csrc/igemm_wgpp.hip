@@ -1,0 +1,404 @@
+// igemm_wgpp: the 3x3 weight-gradient implicit GEMM of igemm_wgrad.hip (128 F channels x 64 S channels x 9 taps per workgroup,
+// pixel tiles of 128, same LDS images, same slabs, same summation order: bit-identical results) run as a PING-PONG between the two
+// waves of every SIMD, like igemm_pp.hip does for the forward convolution.
+//
+// igemm_wgrad's eight waves each read, multiply, compute staging addresses and issue LDS-DMA in one stream: 2.1 non-MFMA vector
+// instructions per MFMA, the matrix pipe ~35-44 % busy. Here a PHASE is one 32-pixel k-step of a pixel tile: 26 transposed LDS reads
+// (4 F fragments, 9 tap-shifted S fragments) and 36 MFMAs (+4 for the bias sums) per wave. Waves 0-3 (G0: F channels 0-63) and
+// waves 4-7 (G1: F channels 64-127; wave w+4 shares its SIMD with wave w) run  R(0) | M(0) | R(1) | M(1) ...  ('|' = workgroup
+// barrier) one interval apart: in every interval one wave of a SIMD does nothing but MFMAs while its partner reads the next k-step's
+// fragments and stages the next tile. Geometry (strip width 2^LSW) is a template constant and the loop is unrolled over the two
+// staging slots, so every LDS address is a per-lane register plus an immediate.
+//
+// Staging: 2 slots (pixel tile t in slot t & 1). Every wave ends an R interval with s_waitcnt lgkmcnt(0), so a slot may be refilled
+// from the interval after its last reader's R: tile t+1 goes into the slot of tile t-1 during the R intervals of tile t's k-steps
+// 0, 1, 2 (three pieces per wave each); the waves wait for all of their pieces (vmcnt(0): nothing else is in flight) at the end of
+// G1's R(3) / behind G0's MFMAs of M(3) -- the same global interval, whose barrier publishes the tile to G0's next R(0).
+#include <type_traits>
+
+#include "igemm.h"
+
+#define RSU_SENT 0x80000000u
+
+namespace {
+// SCH (phases per 32-pixel k-step and what they hold): 0 = two, taps 0-4 (+ the F fragments, the bias sums) | taps 5-8; 3 = two, taps
+// 0-3 | 4-8; 4 = one phase of all nine taps. Pieces (of the 9 a wave stages per tile) issued in the R interval of phase ph:
+constexpr int sched_nph(int sch) { return sch >= 4 ? 1 : 2; }
+constexpr int sched_count(int sch, int ph) {
+    constexpr int T2[8] = {0, 3, 0, 3, 0, 3, 0, 0}, T1[4] = {3, 3, 3, 0};
+    return sch >= 4 ? T1[ph] : T2[ph];
+}
+constexpr int sched_first(int sch, int ph) {
+    int n = 0;
+    for (int i = 0; i < ph; ++i) n += sched_count(sch, i);
+    return n;
+}
+__device__ __forceinline__ void bdma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+}  // namespace
+
+// DBG (timing ablations, RSU_WG_DBG): 1 = no staging after the first tile, 2 = no LDS reads, 4 = no MFMAs, 8 = S reads of taps 0-2 only
+// SCH: phases per k-step and where its taps are split (sched_nph)
+template <int LSW, int DBG, int SCH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgpp_kernel(const IgWgradParams p) {
+    constexpr int NW = 8, NTAP = 9, KW = 3, TMK = 128, CFT = 4;
+    constexpr int SW = 1 << LSW, TR = TMK >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8;
+    constexpr int NPIX = ((TR + 2) * CW + 31) / 32 * 32;   // S halo pixels (plan_geo_aligned)
+    constexpr int NSW = ((NPIX + 7) / 8 + 7) / 8;          // S pieces (8 pixels x 128 bytes) per wave per tile
+    constexpr int NFW = 4;                                 // F pieces per wave per tile: 2 planes x 128 px / 8 px / 8 waves
+    constexpr int FPL = TMK * 128, FBUF = 2 * FPL, SBUF = NSW * NW * 1024;
+    constexpr int SLOT = FBUF + SBUF;                      // LDS: [F tile | S halo tile] x 2 slots
+    static_assert(2 * SLOT <= 160 * 1024 && NFW + NSW <= 9, "staging budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wcs = wave & 3;   // wcf == grp
+    const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
+    // (cfb, csb, z) from an XCD-contiguous numbering: the gx * gy workgroups of one pixel split z read the same F and S pixel tiles
+    // (each F tile gy times, each S tile gx times) -- on one XCD all but the first of those reads are L2 hits
+    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y);
+    const int tpi = p.g.nstrips * p.g.tiles_per_strip;
+    // (the S window is the F image plus a border of one: 3x3 taps, stride 1, dilation 1)
+
+    f32x4 acc[NTAP][CFT];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int a = 0; a < CFT; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // BiasAddGrad rides along (F^T x ones, one MFMA per F tile and k-step), dealt over the four waves of a group: wave wcs keeps the
+    // sums of F tile wcs -- one extra MFMA per k-step on every SIMD and 4 accumulator registers, not four MFMAs on one SIMD and 16.
+    // So that this tile sits in a fixed register, a wave numbers its F tiles from its own: fragment / accumulator column i belongs to
+    // F tile (i + wcs) & 3.
+    const bool do_bias = (p.bslab != nullptr) && (csb == 0);
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS read offsets inside slot 0 (k-step 0, kernel row 0); slot, k-step and row are immediates
+    // (addresses of the CURRENT slot: the offsets of slot 1 do not fit the 16-bit immediate of ds_read, so the registers move by
+    // +-SLOT at every tile switch -- 14 additions per 8 phases -- instead of the loop being unrolled over the slots)
+    int fo[2][CFT];   // F: [half of the k-step][cf tile]
+    int so[2][KW];    // S: [half][kx]
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int ml = rd * 16 + 4 * g4 + q4;
+        const int ch = grp * 64 + 4 * p4;   // F channel of tile 0 of this wave: plane grp, channel 4*p4 inside it
+        const int f0 = (ch >> 6) * FPL + ml * 128 + ((((ch & 63) >> 4) ^ ((ml >> 1) & 3)) << 5) + (ch & 15) * 2;
+#pragma unroll
+        for (int ct = 0; ct < CFT; ++ct) fo[rd][ct] = f0 ^ (((ct + wcs) & 3) << 5);
+        const int ty = ml >> LSW, tx = ml & (SW - 1);
+        const int hp0 = ty * CW + tx;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int hp = hp0 + kx;
+            const int chs = wcs * 16 + 4 * p4;
+            so[rd][kx] = FBUF + hp * 128 + ((((chs >> 4) ^ ((hp >> 1) & 3))) << 5) + (chs & 15) * 2;
+        }
+    }
+    // S byte offset of k-step k inside the halo tile
+    auto sdelta = [](int k) constexpr {
+        const int m0 = k * 32;
+        return ((m0 >> LSW) * CW + (m0 & (SW - 1))) * 128;
+    };
+
+    // ---- staging pieces of this wave: NFW of the F tile, NSW of the S halo tile (8 pixels x 64 channels = 1 KiB each, one LDS-DMA
+    // instruction). The 8 pixels of a piece lie in one row of the tile (SW and CW are multiples of 8) and the channel swizzle depends
+    // on the pixel's low bits only, so a lane's source offset splits into a per-lane part that is the same for every piece and tile
+    // (lvF / lvS: one register each) and a wave-uniform part that rides in the instruction's scalar offset. Interior tiles need no
+    // vector instruction per piece; edge tiles two compares and a select.
+    const int l8 = lane >> 3;
+    const int cswz8 = ((lane & 7) ^ (((l8 >> 1) & 3) << 1)) * 8;   // first channel (of the 64 of the block) this lane loads
+    unsigned lvF = (unsigned)((l8 * p.Cf + cswz8) * 2), lvS = (unsigned)((l8 * p.S.C + cswz8) * 2);
+    asm volatile("" : "+v"(lvF), "+v"(lvS));  // (keep them as registers: rematerialising costs vector instructions per piece)
+    const int limcS = p.S.C - csb * 64, limcF = p.Cf - cfb * 128;   // channels of this block that exist (S: of 64, F: of 128)
+    auto sgpr = [](auto v) { return __builtin_amdgcn_readfirstlane(v); };  // (wave-uniform by construction; said out loud so it stays scalar)
+    // wave-uniform parts of the source offsets that do not depend on the tile: F piece I covers tile row wty + (I & 1) * (64 >> LSW)
+    // from column wtx0 of channel plane I >> 1; S piece Q starts at halo pixel Q * 64 + wave * 8 = row rrQ, column ccQ
+    const int wty = (wave * 8) >> LSW, wtx0 = (wave * 8) & (SW - 1);
+    const unsigned rowF = sgpr((unsigned)(p.Wf * p.Cf * 2) * (64 >> LSW));
+    const unsigned wbF = sgpr((unsigned)((wty * p.Wf + wtx0) * p.Cf * 2));
+    unsigned wbS[NSW];
+#pragma unroll
+    for (int q = 0; q < NSW; ++q) {
+        const int hp0 = q * 64 + wave * 8, rr = hp0 / CW, cc0 = hp0 - rr * CW;
+        wbS[q] = sgpr((unsigned)((rr * p.S.W + cc0) * p.S.C * 2));
+    }
+    constexpr int HROWS = (NPIX - 1) / CW + 1;  // rows of the staged halo image (its last, partial row is rounding)
+    // per tile: byte offsets of its F and S windows, whether the whole tile lies inside the tensors, and what is left of them from (y0, x0) on
+    struct Tile { unsigned bF, bS; int insF, insS, ry, rx; };
+    // this workgroup's tiles are z, z + nsplit, ...: (image, strip, row in strip) of the first one by division, then stepped -- a
+    // run-time division costs ~40 vector instructions, which an R interval does not have
+    struct Pos { int n, strip, row; };
+    auto split = [&](int t) {
+        Pos q;
+        q.n = t / tpi;
+        const int r = t - q.n * tpi;
+        q.strip = r / p.g.tiles_per_strip;
+        q.row = r - q.strip * p.g.tiles_per_strip;
+        return Pos{sgpr(q.n), sgpr(q.strip), sgpr(q.row)};
+    };
+    const Pos step = split(p.nsplit);
+    auto advance = [&](Pos& q) {
+        q.row += step.row;
+        if (q.row >= p.g.tiles_per_strip) { q.row -= p.g.tiles_per_strip; ++q.strip; }
+        q.strip += step.strip;
+        if (q.strip >= p.g.nstrips) { q.strip -= p.g.nstrips; ++q.n; }
+        q.n += step.n;
+    };
+    auto decode = [&](const Pos& q) {
+        Tile T;
+        const int x0 = q.strip * SW, y0 = q.row * TR;
+        T.bF = sgpr((unsigned)((((long)(q.n * p.Hf + y0) * p.Wf + x0) * p.Cf + cfb * 128) * 2) + wbF);
+        T.bS = sgpr((unsigned)((((long)(q.n * p.S.H + y0 + p.S.oy) * p.S.W + x0 + p.S.ox) * p.S.C + csb * 64) * 2));
+        T.ry = sgpr(p.Hf - y0);
+        T.rx = sgpr(p.Wf - x0);
+        T.insF = (int)(TR <= T.ry) & (int)(SW <= T.rx) & (int)(limcF >= 128);
+        T.insS = (int)(HROWS <= T.ry + 2) & (int)(CW <= T.rx + 2) & (int)(limcS >= 64);
+        return T;
+    };
+    auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
+    // piece i (0 .. NFW+NSW-1) of tile T into slot `buf`: F pieces first
+    auto issue_piece = [&](const Tile& T, auto ic, int buf) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I < NFW) {
+            const __amdgpu_buffer_rsrc_t rf = mk(p.F);
+            const unsigned soff = T.bF + (I & 1) * rowF + (I >> 1) * 128;
+            unsigned vo = lvF;
+            if (!T.insF) {
+                const int ty = wty + (I & 1) * (64 >> LSW);
+                const int limx = ty < T.ry ? T.rx - wtx0 : 0, limc = limcF - (I >> 1) * 64;
+                vo = (l8 < limx && cswz8 < limc) ? lvF : RSU_SENT;
+            }
+            bdma16w(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
+        } else if constexpr (I < NFW + NSW) {
+            constexpr int Q = I - NFW;
+            const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
+            const unsigned soff = T.bS + wbS[Q];
+            constexpr bool whole = NPIX >= (Q + 1) * 64;   // every wave's piece Q lies inside the halo tile
+            unsigned vo = lvS;
+            if (!whole || !T.insS) {
+                const int hp0 = Q * 64 + wave * 8, rr = hp0 / CW, cc0 = hp0 - rr * CW;
+                const int limx = (hp0 < NPIX && rr < T.ry + 2) ? T.rx + 2 - cc0 : 0;
+                vo = (l8 < limx && cswz8 < limcS) ? lvS : RSU_SENT;
+            }
+            bdma16w(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
+        }
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto tr_read = [&](int off) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds + off));
+    };
+
+    // ---- prologue: the first tile of this split, all of it; G1 then sits out interval 0
+    int tile = z;
+    Pos pos = split(tile);   // of the tile staged last
+    {
+        const Tile T0 = decode(pos);
+        issue_piece(T0, std::integral_constant<int, 0>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 1>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 2>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 3>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 4>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 5>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 6>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 7>{}, 0);
+        issue_piece(T0, std::integral_constant<int, 8>{}, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (grp) bar();
+
+    auto run = [&](auto gconst) {
+        constexpr int G = decltype(gconst)::value;
+        int buf = 0;  // slot of the current tile (wave-uniform)
+        // the tile after the current one (staged while the current one is multiplied); looked up in the LAST R interval of the tile
+        // before, which has no staging to do, together with the move of the read addresses to the other slot
+        int nxt = 0;
+        bool have_nxt = false;
+        Tile TN = Tile{0, 0, 0, 0, 0, 0};
+        auto look_ahead = [&]() {
+            nxt = tile + p.nsplit;
+            have_nxt = nxt < p.ntiles_total && !(DBG & 1);
+            if (have_nxt) {
+                advance(pos);
+                TN = decode(pos);
+            }
+        };
+        look_ahead();
+        auto do_tile = [&]() {
+            // (two-phase schedules: the F fragments of a k-step are read in its first phase and stay for the second)
+            bf16x8 fa[CFT];
+            auto phase = [&](auto ksc, auto hc) {
+                constexpr int K = decltype(ksc)::value, HB = decltype(hc)::value;
+                constexpr int NPH = sched_nph(SCH), TSPL = SCH == 3 ? 4 : 5;
+                constexpr int T0 = NPH == 1 ? 0 : (HB ? TSPL : 0), T1 = NPH == 1 ? NTAP : (HB ? NTAP : TSPL), NSV = NPH == 1 ? NTAP : 5;
+                constexpr int PH = NPH * K + HB, LAST = NPH * 4 - 1;
+                constexpr int P0 = sched_first(SCH, PH), PN = sched_count(SCH, PH);
+                // ================= R interval
+                bf16x8 sv[NSV];
+                if constexpr (DBG & 2) {
+                    if constexpr (HB == 0) {
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) asm volatile("" : "=v"(fa[ct]));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NSV; ++i) asm volatile("" : "=v"(sv[i]));
+                } else {
+                    if constexpr (HB == 0) {
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) {
+                            const bf16x4 lo = tr_read(fo[0][ct] + K * 32 * 128), hi = tr_read(fo[1][ct] + K * 32 * 128);
+                            fa[ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                    }
+#pragma unroll
+                    for (int tap = T0; tap < T1; ++tap) {
+                        if ((DBG & 8) && tap >= 3) {  // (timing: a third of the S reads)
+                            asm volatile("" : "=v"(sv[tap - T0]));
+                            continue;
+                        }
+                        const int ky = tap / KW, kx = tap - ky * KW;
+                        const int off = ky * CW * 128 + sdelta(K);
+                        const bf16x4 lo = tr_read(so[0][kx] + off), hi = tr_read(so[1][kx] + off);
+                        sv[tap - T0] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                if constexpr (PN > 0) {
+                    if (have_nxt) {
+                        issue_piece(TN, std::integral_constant<int, P0>{}, buf ^ 1);
+                        if constexpr (PN > 1) issue_piece(TN, std::integral_constant<int, P0 + 1>{}, buf ^ 1);
+                        if constexpr (PN > 2) issue_piece(TN, std::integral_constant<int, P0 + 2>{}, buf ^ 1);
+                    }
+                }
+                if constexpr (PH == LAST) {
+                    // (the reads above carry the old addresses; everything below belongs to the next tile)
+                    tile = nxt;
+                    const int mv = buf ? -SLOT : SLOT;
+                    buf ^= 1;
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) {
+                            fo[rd][ct] += mv;
+                            asm volatile("" : "+v"(fo[rd][ct]));  // (here, not in the next tile's busier first R interval)
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < KW; ++kx) {
+                            so[rd][kx] += mv;
+                            asm volatile("" : "+v"(so[rd][kx]));
+                        }
+                    }
+                    look_ahead();
+                    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // G1's pieces of the next tile (nothing else is in flight)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers: this slot may be refilled from the next interval on
+                bar();
+                // ================= M interval: MFMAs only
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if constexpr (DBG & 4) {
+#pragma unroll
+                    for (int tap = T0; tap < T1; ++tap) asm volatile("" :: "v"(sv[tap - T0]), "v"(fa[tap & 3]));
+                } else {
+#pragma unroll
+                    for (int tap = T0; tap < T1; ++tap)
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) mfma_bf16_inplace(acc[tap][ct], fa[ct], sv[tap - T0]);
+                }
+                if (!(DBG & 4) && HB == 0 && do_bias) {
+                    unsigned o1 = 0x3f803f80u;
+                    asm volatile("" : "+v"(o1));
+                    const u32x4 o4 = {o1, o1, o1, o1};
+                    bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                    asm volatile("s_nop 3" : "+v"(ones));  // VALU-written operand -> (asm) MFMA read: the hazard recogniser cannot see it
+                    mfma_bf16_inplace(accb, fa[0], ones);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PH == LAST && G == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // G0's pieces of the next tile
+                bar();
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            phase(I0{}, I0{});
+            if constexpr (sched_nph(SCH) == 2) phase(I0{}, I1{});
+            phase(I1{}, I0{});
+            if constexpr (sched_nph(SCH) == 2) phase(I1{}, I1{});
+            phase(I2{}, I0{});
+            if constexpr (sched_nph(SCH) == 2) phase(I2{}, I1{});
+            phase(I3{}, I0{});
+            if constexpr (sched_nph(SCH) == 2) phase(I3{}, I1{});
+        };
+        while (tile < p.ntiles_total) do_tile();
+    };
+    if (grp) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+    if (!grp) bar();  // G0 sits out G1's last M interval
+    mfma_results_fence();
+
+    // ---- outputs: bias sums (every column of accb holds the same sums: column 0 writes them) and this split's slab
+    const int zs = z;
+    if (do_bias && l15 == 0) {
+        const int cf = cfb * 128 + (grp * CFT + wcs) * 16 + 4 * g4;
+        if (cf < p.Cf) *(f32x4*)(p.bslab + (long)zs * p.slab_stride + cf) = accb;
+    }
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+        const int cs = csb * 64 + wcs * 16 + l15;
+        if (cs >= p.S.C) continue;
+#pragma unroll
+        for (int ct = 0; ct < CFT; ++ct) {
+            const int cf = cfb * 128 + (grp * CFT + ((ct + wcs) & 3)) * 16 + 4 * g4;
+            if (cf >= p.Cf) continue;
+            float* dst = p.slab + (long)zs * p.slab_stride + (((long)tap * p.CsOut + p.cs_off + cs) * p.CfOut + cf);
+            *(f32x4*)dst = acc[tap][ct];
+        }
+    }
+}
+
+template <int LSW, int DBG = 0, int SCH = 4>
+static hipError_t wgpp_launch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    constexpr int SW = 1 << LSW, TR = 128 >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32, NSW = ((NPIX + 7) / 8 + 7) / 8;
+    if (p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX || p.nsw != NSW) return hipErrorInvalidValue;
+    auto kern = igemm_wgpp_kernel<LSW, DBG, SCH>;
+    const size_t lds = 2 * (size_t)(2 * 128 * 128 + NSW * 8 * 1024);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+// the launches igemm_wgpp is built for: the 128x64 shape of the 3x3 stride-1 dilation-1 weight gradient with the planner's halo tile
+bool igemm_wgpp_supports(int cfg, int ntap, const IgWgradParams& p) {
+    if (cfg != IGW_CFG_128x64 || ntap != 9 || p.stride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
+    const int SW = 1 << p.lsw, TR = 128 >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32, NSW = ((NPIX + 7) / 8 + 7) / 8;
+    return p.g.SW == SW && p.g.CW == CW && p.g.npix_max == NPIX && p.nsw == NSW && NSW + 4 <= 9 &&
+           2 * (2 * 128 * 128 + NSW * 8 * 1024) <= 160 * 1024;
+}
+hipError_t igemm_wgpp_launch(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    if (p.dbg) {  // timing ablations / schedule variants (strip width 16 and 32 only): RSU_WG_DBG = 16 * SCH + DBG
+#define WGPP_CASE(L, S, D) if (p.lsw == L && p.dbg == 16 * S + D) return wgpp_launch_one<L, D, S>(p, gx, gy, gz, st)
+#define WGPP_CASES(L, S) WGPP_CASE(L, S, 0); WGPP_CASE(L, S, 1); WGPP_CASE(L, S, 2); WGPP_CASE(L, S, 3); WGPP_CASE(L, S, 4); WGPP_CASE(L, S, 5); WGPP_CASE(L, S, 7); WGPP_CASE(L, S, 9)
+        WGPP_CASES(4, 0); WGPP_CASES(5, 0); WGPP_CASES(4, 4); WGPP_CASES(5, 4); WGPP_CASE(4, 3, 0); WGPP_CASE(5, 3, 0);
+#undef WGPP_CASES
+#undef WGPP_CASE
+    }
+    switch (p.lsw) {
+        case 3: return wgpp_launch_one<3>(p, gx, gy, gz, st);
+        case 4: return wgpp_launch_one<4>(p, gx, gy, gz, st);
+        case 5: return wgpp_launch_one<5>(p, gx, gy, gz, st);
+        case 6: return wgpp_launch_one<6>(p, gx, gy, gz, st);
+    }
+    return hipErrorInvalidValue;
+}

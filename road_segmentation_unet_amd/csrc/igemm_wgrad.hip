@@ -55,7 +55,10 @@ igemm_wgrad_kernel(const IgWgradParams p) {
     const int kgrp = wave / (WCF * WCS), wave4 = wave % (WCF * WCS);
     const int wcf = wave4 / WCS, wcs = wave4 % WCS;
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
-    const int cfb = blockIdx.x, csb = blockIdx.y, z = blockIdx.z;
+    // (cfb, csb, z) from an XCD-contiguous numbering: the gx * gy workgroups of one pixel split z read the same F and S pixel tiles
+    // (each F tile gy times, each S tile gx times) -- on one XCD all but the first of those reads are L2 hits
+    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y);
     const int zs = z;  // slab of this workgroup
     const int SW = p.g.SW, CW = p.g.CW, lsw = p.lsw, TR = TMK >> lsw;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;

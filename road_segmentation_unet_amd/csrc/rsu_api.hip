@@ -696,7 +696,11 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.nsw = igemm_wgrad_nsw(cfg, pl.g.npix_max);
     p.dbg = env_int("RSU_WG_DBG", 0);
     p.g = pl.g;
-    HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
+    // RSU_WG_GEN=1: igemm_wgrad everywhere; default: the ping-pong kernel where it is built (same slabs, same bits)
+    if (env_int("RSU_WG_GEN", 2) >= 2 && igemm_wgpp_supports(cfg, ntap, p))
+        HIP_CHECK_RET(igemm_wgpp_launch(p, pl.gx, pl.gy, pl.nsplit, st));
+    else
+        HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
     if (nslab > 1) {
         HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
     }

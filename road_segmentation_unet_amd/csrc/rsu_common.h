@@ -65,6 +65,13 @@ __device__ __forceinline__ unsigned relu_mask_from_bits(unsigned b, int i) {
 __device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+// XCD-aware workgroup numbering for one-workgroup-per-CU launches: the dispatcher deals consecutive workgroup ids round-robin over the 8
+// XCDs (id & 7), each with its own L2. This turns the hardware id into a logical id such that each XCD owns a CONTIGUOUS range of logical
+// ids: workgroups that share operand tiles (neighbouring logical ids) then fetch them through one L2 instead of eight.
+__device__ __forceinline__ int xcd_contiguous_id(int hw_id, int total) {
+    const int q = total >> 3, r = total & 7, x = hw_id & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (hw_id >> 3);
+}
 __device__ __forceinline__ void mfma_results_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // ---- async global -> LDS copy, 16 bytes per lane (LDS destination = wave-uniform base + lane*16)

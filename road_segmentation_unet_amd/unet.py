@@ -104,6 +104,7 @@ class UNet:
         self.keep = 1.0        # dropout keep probability of the forward pass in flight (set by forward_device)
         self.dropout_seed = int(seed) if seed is not None else 0
         self.wstream = None    # second stream for the weight-gradient launches (see _Side)
+        self._split = None     # (full, main, side) CU budgets while a backward pass shares the chip between the two streams
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             self.wstream = torch.cuda.Stream(device=self.device)
         self.bits, self._bits_of = {}, {}
@@ -311,14 +312,39 @@ class UNet:
     # Weight-gradient launches can go to a second stream: they only READ what the main stream produced (dz, activations) and
     # write gradients nobody reads before the optimizer. Two persistent kernels then share the chip and each fills the other's
     # poorly occupied last round of tiles. RSU_WGRAD_STREAM=0 keeps everything on one stream.
+    #
+    # The two streams SHARE the chip by plan (RSU_SPLIT_CHIP, default "128,128" of 256): while the backward pass runs, launches on
+    # the main stream (backward-data) plan their persistent workgroups for the first number of CUs, launches on the side stream
+    # (weight gradients) for the second, so a backward-data and a weight-gradient kernel are resident together, each on its
+    # own CUs, instead of taking turns on all of them. The weight gradient of a layer is a sum over one partial result PER
+    # WORKGROUP (a 295-KB slab each, written and read back by the reduce kernel): half the workgroups, half that traffic --
+    # and persistent kernels on fewer CUs lose less to their last, partly filled round of tiles. "0" = both plan for every CU.
+    def _begin_split(self):
+        self._split = None
+        spec = os.environ.get("RSU_SPLIT_CHIP", "128,128")
+        if self.wstream is None or spec in ("0", ""):
+            return
+        full = _lib.lib().rsu_get_cu_budget()
+        a, b = (int(v) for v in (spec.split(",") if "," in spec else ("128", "128")))
+        a, b = max(32, a * full // 256 // 8 * 8), max(32, b * full // 256 // 8 * 8)  # (a data-parallel run may have lowered the budget)
+        self._split = (full, a, b)
+        call("rsu_set_cu_budget", a)
+
+    def _end_split(self):
+        if self._split is not None:
+            call("rsu_set_cu_budget", self._split[0])
+            self._split = None
+
     class _Side:
-        def __init__(self, net):
-            self.net, self.ctx = net, None
+        def __init__(self, net, alone=False):
+            self.net, self.ctx, self.alone = net, None, alone  # alone: nothing is left to run beside it on the main stream
 
         def __enter__(self):
             n = self.net
             if n.wstream is None:
                 return
+            if n._split is not None:
+                call("rsu_set_cu_budget", n._split[0] if self.alone else n._split[2])
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(n.device))
             n.wstream.wait_event(ev)
@@ -328,6 +354,8 @@ class UNet:
         def __exit__(self, *a):
             if self.ctx is not None:
                 self.ctx.__exit__(*a)
+                if self.net._split is not None:
+                    call("rsu_set_cu_budget", self.net._split[1])
 
     def _join_side(self):
         if self.wstream is not None:
@@ -452,6 +480,7 @@ class UNet:
         B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
         keep = self.keep
         last = a[self.last_name]
+        self._begin_split()
         self.loss_sum.zero_()
         call("rsu_head_fwd_bwd", _ptr(last), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.labels),
              _ptr(self.prob), _ptr(self.loss_sum), _ptr(g[self.last_name]), _ptr(self.g["weight_output/kernel"]),
@@ -502,7 +531,7 @@ class UNet:
                 self._wgrad("conv_%d/conv1" % i, [(pin, h)], dz1, h - 2)
                 self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
             else:
-                with UNet._Side(self):
+                with UNet._Side(self, alone=not (self.dilated and L > 1)):
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
                          _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B, h, h, nf, 1, self._stream())
             if self.dilated and i < L - 1:
@@ -518,7 +547,7 @@ class UNet:
                     self._wgrad("conv_dilut_%d/atrous_conv1" % i, [(pin, h)], dzd1, h - 4, dil=2)
                     self._bwd_data("conv_dilut_%d/atrous_conv1" % i, dzd1, g["pool_%d" % (i - 1)], h, accumulate=1, dil=2)
                 else:
-                    with UNet._Side(self):
+                    with UNet._Side(self, alone=True):
                         call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
                              _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, self._stream())
             if i > 0:
@@ -527,6 +556,7 @@ class UNet:
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if (self.dilated and i < L - 1) else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
         self._join_side()
+        self._end_split()
         # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
         #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
         inv_keep = float(np.float32(1.0) / np.float32(keep))

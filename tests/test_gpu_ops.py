@@ -151,6 +151,28 @@ def test_conv2d_bwd_weight_and_bias(N, H, W, Cin, Cout, dil):
         hu.assert_f32_close(hu.host(db), ref_db, "bias_grad")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 30, 30, 64, 128), (1, 70, 70, 128, 256), (3, 21, 37, 72, 136), (1, 12, 140, 128, 128),
+                                            (2, 10, 10, 256, 512)])
+def test_pingpong_wgrad_gives_the_bits_of_igemm_wgrad(N, H, W, Cin, Cout, monkeypatch):
+    """igemm_wgpp (RSU_WG_GEN=2, the default) keeps igemm_wgrad's tiles, slabs and summation order: same bits, bias sums included"""
+    rng = np.random.RandomState(Cin + Cout + H)
+    Ho, Wo = H - 2, W - 2
+    xd = hu.dev_bf16(hu.q(_rand(rng, N, H, W, Cin)))
+    dzd = hu.dev_bf16(hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1)))
+    nws = lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout)
+    out = {}
+    for gen in ("1", "2"):
+        monkeypatch.setenv("RSU_WG_GEN", gen)
+        dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+        db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+        ws = torch.zeros(nws, dtype=torch.float32, device=hu.DEV)
+        s = hu.src_of(xd, H, W)
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, hu.stream())
+        out[gen] = (hu.host(dw), hu.host(db))
+    assert np.array_equal(out["1"][0].view(np.uint32), out["2"][0].view(np.uint32)), "weight gradient bits differ"
+    assert np.array_equal(out["1"][1].view(np.uint32), out["2"][1].view(np.uint32)), "bias gradient bits differ"
+
+
 def test_conv2d_bwd_weight_cropped_sources():
     rng = np.random.RandomState(10)
     N, h = 2, 24

@@ -101,7 +101,7 @@ def main():
         fl = 2.0 * B * ho * ho * cout * cin * 9
         line = "%-14s H%4d C%4d->%4d d%d %7.1f GF |" % (name, hin, cin, cout, dil, fl / 1e9)
         for op in ops:
-            for cfg, gen, dbg in [(c, g, d) for c in (cfgs if op != "wg" else [-1]) for g in (gens if op != "wg" else [None]) for d in (dbgs if op != "wg" else [None])]:
+            for cfg, gen, dbg in [(c, g, d) for c in (cfgs if not op.startswith("wg") else [-1]) for g in (gens if not op.startswith("wg") else [None]) for d in (dbgs if not op.startswith("wg") else [None])]:
                 if gen is not None:
                     os.environ["RSU_FWD_GEN"] = gen
                 if dbg is not None:
@@ -117,7 +117,11 @@ def main():
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, st))
                     elif op == "bwdnm":  # backward-data without the ReLU mask (A/B: cost of the mask loads in the epilogue)
                         t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, st))
-                    else:
+                    else:  # "wg", or "wg1" / "wg2" = igemm_wgrad / igemm_wgpp (RSU_WG_GEN)
+                        if len(op) > 2:  # "wg2d3" = generation 2 with RSU_WG_DBG=3 (timing ablation)
+                            g_, _, d_ = op[2:].partition("d")
+                            os.environ["RSU_WG_GEN"] = g_
+                            os.environ["RSU_WG_DBG"] = d_ or "0"
                         t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, st))
                     tag = ("" if cfg < 0 else "[%d]" % cfg) + ("" if gen is None else "g" + gen) + ("" if dbg is None else "d" + dbg)
                     line += " %s%s %6.0fus %5.0fTF |" % (op, tag, t * 1e6, fl / t / 1e12)
@@ -127,6 +131,8 @@ def main():
         os.environ.pop("RSU_FWD2_CFG", None)
         os.environ.pop("RSU_FWD_GEN", None)
         os.environ.pop("RSU_FWD_DBG", None)
+        os.environ.pop("RSU_WG_GEN", None)
+        os.environ.pop("RSU_WG_DBG", None)
         print(line, flush=True)
     print("totals (ms):", {k: round(v * 1e3, 3) for k, v in tot.items()})
 
