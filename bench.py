@@ -164,7 +164,7 @@ def main():
     bucketer = None
     if world > 1:
         bucketer = GradBucketer(m.flat_g, m.n_live)
-        bucketer.extra_streams = [m.wstream]
+        bucketer.extra_streams = list(m.wstreams)
         m.on_grads = bucketer.ready
     lr, mu = 0.01, 0.9
 
@@ -227,11 +227,11 @@ def main():
     # backward-data launches, which stretches every launch it overlaps; the roofline figure wants each kernel's own duration)
     nprof = 3
     m.prof = []
-    wstream, m.wstream = m.wstream, None
+    wstreams, m.wstreams = m.wstreams, []
     for _ in range(nprof):
         run_step(m, bucketer, lr, mu)
     torch.cuda.synchronize()
-    m.wstream = wstream
+    m.wstreams = wstreams
     agg = {}
     for tag, fl, e0, e1 in m.prof:
         a = agg.setdefault(tag, [0.0, 0.0, 0])

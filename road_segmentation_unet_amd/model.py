@@ -121,7 +121,7 @@ class ConvolutionalModel:
         self._pending_scalars = []
         if self.world > 1:
             self._bucketer = GradBucketer(self.net.flat_g, self.net.n_live)
-            self._bucketer.extra_streams = [self.net.wstream]
+            self._bucketer.extra_streams = list(self.net.wstreams)
             self.net.on_grads = self._bucketer.ready
             # identical initial weights on every rank (the reference has one copy; ranks must start from the same point)
             dist.broadcast(self.net.flat_w, 0)

@@ -20,6 +20,9 @@ NUM_CHANNELS = 3  # src/constants.py:3
 NUM_LABELS = 2    # src/constants.py:4
 
 
+_SPLIT_DEFAULT = "128,128"   # RSU_SPLIT_CHIP: CUs the main stream / each side stream plan for during the backward pass (UNet._Side)
+
+
 def input_size_needed(output_size, num_layers):
     """Utility function to compute image size for a given U-Net output (reference: unet.py:100-115).
 
@@ -103,10 +106,14 @@ class UNet:
         self.training = training
         self.keep = 1.0        # dropout keep probability of the forward pass in flight (set by forward_device)
         self.dropout_seed = int(seed) if seed is not None else 0
-        self.wstream = None    # second stream for the weight-gradient launches (see _Side)
-        self._split = None     # (full, main, side) CU budgets while a backward pass shares the chip between the two streams
+        self.wstream = None    # side stream for the weight-gradient launches (see _Side); wstreams: all of them
+        self.wstreams = []
+        self._split = None     # (full, main, [side ...]) CU budgets while a backward pass shares the chip between the streams
+        self._side_rr = 0
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
-            self.wstream = torch.cuda.Stream(device=self.device)
+            nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
+            self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
+            self.wstream = self.wstreams[0]
         self.bits, self._bits_of = {}, {}
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
@@ -219,6 +226,8 @@ class UNet:
                 if n.startswith("up_conv") and n.endswith("kernel"):
                     ws.append(lib.rsu_convT2x2_bwd_weight_ws_floats(s[3], s[2]))
             self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
+            # (one workspace per stream that launches weight gradients: their slabs are live at the same time)
+            self.ws_side = [self.ws] + [torch.zeros_like(self.ws) for _ in self.wstreams[1:]]
             # 1-bit ReLU masks of the conv1 / atrous_conv1 outputs (the ReluGrad masks of the conv2 backward-data launches): written by
             # the forward conv beside its activation, read instead of it in backward (16x fewer bytes). Built and tested, but OFF by default (RSU_RELU_BITS=1 turns it on): measured -0.8 % on the step -- what the bf16 mask costs backward-data is one exposed round trip per tile, not its bytes, and the forward epilogue pays for building the bits.
             self.bits = {}
@@ -313,7 +322,7 @@ class UNet:
     # write gradients nobody reads before the optimizer. Two persistent kernels then share the chip and each fills the other's
     # poorly occupied last round of tiles. RSU_WGRAD_STREAM=0 keeps everything on one stream.
     #
-    # The two streams SHARE the chip by plan (RSU_SPLIT_CHIP, default "128,128" of 256): while the backward pass runs, launches on
+    # The two streams SHARE the chip by plan (RSU_SPLIT_CHIP, default _SPLIT_DEFAULT, of 256): while the backward pass runs, launches on
     # the main stream (backward-data) plan their persistent workgroups for the first number of CUs, launches on the side stream
     # (weight gradients) for the second, so a backward-data and a weight-gradient kernel are resident together, each on its
     # own CUs, instead of taking turns on all of them. The weight gradient of a layer is a sum over one partial result PER
@@ -321,14 +330,16 @@ class UNet:
     # and persistent kernels on fewer CUs lose less to their last, partly filled round of tiles. "0" = both plan for every CU.
     def _begin_split(self):
         self._split = None
-        spec = os.environ.get("RSU_SPLIT_CHIP", "128,128")
-        if self.wstream is None or spec in ("0", ""):
+        spec = os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT)
+        if not self.wstreams or spec in ("0", ""):
             return
         full = _lib.lib().rsu_get_cu_budget()
-        a, b = (int(v) for v in (spec.split(",") if "," in spec else ("128", "128")))
-        a, b = max(32, a * full // 256 // 8 * 8), max(32, b * full // 256 // 8 * 8)  # (a data-parallel run may have lowered the budget)
-        self._split = (full, a, b)
-        call("rsu_set_cu_budget", a)
+        parts = [int(v) for v in spec.split(",")]
+        if len(parts) != len(self.wstreams) + 1:
+            return
+        parts = [max(32, v * full // 256 // 8 * 8) for v in parts]  # (a data-parallel run may have lowered the budget)
+        self._split = (full, parts[0], parts[1:])
+        call("rsu_set_cu_budget", parts[0])
 
     def _end_split(self):
         if self._split is not None:
@@ -336,20 +347,27 @@ class UNet:
             self._split = None
 
     class _Side:
+        """`with UNet._Side(net) as side:` -- launches inside go to the next side stream (round robin); side.ws is its workspace"""
+
         def __init__(self, net, alone=False):
             self.net, self.ctx, self.alone = net, None, alone  # alone: nothing is left to run beside it on the main stream
+            self.ws = net.ws if net.training else None
 
         def __enter__(self):
             n = self.net
-            if n.wstream is None:
-                return
+            if not n.wstreams:
+                return self
+            k = n._side_rr % len(n.wstreams)
+            n._side_rr += 1
+            self.ws = n.ws_side[k]
             if n._split is not None:
-                call("rsu_set_cu_budget", n._split[0] if self.alone else n._split[2])
+                call("rsu_set_cu_budget", n._split[0] if self.alone else n._split[2][k])
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(n.device))
-            n.wstream.wait_event(ev)
-            self.ctx = torch.cuda.stream(n.wstream)
+            n.wstreams[k].wait_event(ev)
+            self.ctx = torch.cuda.stream(n.wstreams[k])
             self.ctx.__enter__()
+            return self
 
         def __exit__(self, *a):
             if self.ctx is not None:
@@ -358,8 +376,8 @@ class UNet:
                     call("rsu_set_cu_budget", self.net._split[1])
 
     def _join_side(self):
-        if self.wstream is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.wstream)
+        for s in self.wstreams:
+            torch.cuda.current_stream(self.device).wait_stream(s)
 
     def _conv(self, name, srcs, hin, out, dil=1):
         arr = (RsuSrc * len(srcs))(*srcs)
@@ -452,13 +470,13 @@ class UNet:
         cout = dz.shape[3]
         cin_total = self.w[name + "/kernel"].shape[2]
         off = 0
-        with UNet._Side(self):
+        with UNet._Side(self) as side:
             st = self._stream()
             for t, win in srcs_t:
                 s = _src(t, win, win)
                 db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
                 self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
-                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(self.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
+                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
                 off += t.shape[3]
 
     def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
@@ -507,9 +525,9 @@ class UNet:
             if keep < 1.0:  # the transposed conv read the dropped tensor; (dropped > 0) = ReLU mask AND keep mask
                 upin = a["drop_%d" % i]
             hh = h // 2
-            with UNet._Side(self):
+            with UNet._Side(self) as side:
                 call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
-                     _ptr(self.ws), B, hh, hh, upin.shape[3], nf, self._stream())
+                     _ptr(side.ws), B, hh, hh, upin.shape[3], nf, self._stream())
             call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), float(np.float32(1.0) / np.float32(keep)), B, hh, hh,
                  upin.shape[3], nf, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
@@ -531,9 +549,9 @@ class UNet:
                 self._wgrad("conv_%d/conv1" % i, [(pin, h)], dz1, h - 2)
                 self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
             else:
-                with UNet._Side(self, alone=not (self.dilated and L > 1)):
+                with UNet._Side(self, alone=not (self.dilated and L > 1)) as side:
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
-                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws), B, h, h, nf, 1, self._stream())
+                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._stream())
             if self.dilated and i < L - 1:
                 d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
@@ -547,9 +565,9 @@ class UNet:
                     self._wgrad("conv_dilut_%d/atrous_conv1" % i, [(pin, h)], dzd1, h - 4, dil=2)
                     self._bwd_data("conv_dilut_%d/atrous_conv1" % i, dzd1, g["pool_%d" % (i - 1)], h, accumulate=1, dil=2)
                 else:
-                    with UNet._Side(self, alone=True):
+                    with UNet._Side(self, alone=True) as side:
                         call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
-                             _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(self.ws), B, h, h, nf, 2, self._stream())
+                             _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(side.ws), B, h, h, nf, 2, self._stream())
             if i > 0:
                 # first LIVE variable of the level in creation order: the dilated pair of level L-1 is dead and sits behind n_live
                 # (marking it ready launched nothing, and the largest block waited for level L-2)

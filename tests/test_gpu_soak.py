@@ -49,14 +49,17 @@ def test_short_training_runs_are_bit_identical():
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
-def test_two_stream_schedule_does_not_change_the_numbers():
-    """The weight-gradient launches run on a second stream by default; the same steps on one stream must give the same bits."""
+def test_two_stream_schedule_does_not_change_the_numbers(monkeypatch):
+    """The weight-gradient launches run on side streams by default; the same steps on one stream must give the same bits (with
+    every launch planned for the whole chip: RSU_SPLIT_CHIP=0), and the same numbers to summation order with the chip shared out
+    between the streams (fewer, longer partial sums per weight gradient)."""
     from road_segmentation_unet_amd.unet import UNet
 
-    def run(single_stream):
+    def run(single_stream, split="0"):
+        monkeypatch.setenv("RSU_SPLIT_CHIP", split)
         m = UNet(4, 32, True, 2, 204, seed=11, training=True)
         if single_stream:
-            m.wstream = None
+            m.wstream, m.wstreams = None, []
         g = torch.Generator(device="cpu").manual_seed(3)
         for _ in range(6):
             m.x.copy_(torch.rand((2, m.S, m.S, 3), generator=g))
@@ -69,6 +72,9 @@ def test_two_stream_schedule_does_not_change_the_numbers():
 
     a, b = run(False), run(True)
     assert torch.equal(a, b)
+    for split in ("128,128", "128,64,64"):
+        c = run(False, split)
+        assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), split
 
 
 def test_measured_tile_shapes_do_not_change_the_numbers():
