@@ -58,6 +58,29 @@ bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
 bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
 
 // ---------------------------------------------------------------------------------------------
+// igemm_ct (igemm_ct.hip): the 2x2 stride-2 transposed convolution as a ping-pong GEMM over the low-resolution pixels m = (n, y, x)
+//   mode 0, forward      : a = x [N][H][W][Ca],   out = y [N][2H][2W][outC], Cn = Cout; packed weights = rsu_pack_convT_fwd's 4 phases
+//   mode 1, backward-data: a = dy [N][2H][2W][Ca], out = dx [N][H][W][outC],  Cn = Cin;  packed weights = rsu_pack_convT_bwd's 4 taps
+struct IgCtParams {
+    const bf16_t* a;
+    int Ca;               // channels per pixel of a (the reduction length per tap), multiple of 8
+    int nchunk;           // ceil(Ca / 32)
+    int N, H, W;          // low-resolution grid; N * H * W < 2^24
+    unsigned magic_hw, magic_w;   // floor(2^32 / (H * W)), floor(2^32 / W) (0xffffffff for a divisor of 1): one multiply-high + one fix-up per division
+    const bf16_t* wp;
+    long wp_phase_stride; // elements between the packed matrices of two output phases (mode 0)
+    int ntiles_w;         // 16-row tiles per (chunk, tap) block of wp
+    const float* bias;    // [Cn] or null (mode 0)
+    bf16_t* out;
+    int outC;             // channel pitch of out
+    int Cn;               // channels produced (mode 0: per output phase; a workgroup column = b * Cn + co)
+    const bf16_t* mask_src;  // mode 1: ReLU mask source with the geometry of out, or null
+    int ncob, nnb;        // column blocks of 128 per launch; mode 0: ncob = 2 row phases x nnb
+};
+bool igemm_ct_supports(int mode, int N, int H, int W, int Ca, int Cn);
+hipError_t igemm_ct_launch(int mode, const IgCtParams& p, int grid_x, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
 // igemm_wgrad: slab[z][tap][cs_off+cs][cf] = sum_{pix in split z} S[n][pix*stride + tap*dil][cs] * F[n][pix][cf]
 //   conv3x3 backward-weight : F = dz (cf = co), S = layer input (cs = ci), 9 taps
 //   convT 2x2 backward-weight: F = x (cf = ci), S = dy (cs = co), 4 taps, stride 2

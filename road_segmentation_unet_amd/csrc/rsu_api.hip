@@ -586,6 +586,36 @@ extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void*
                    3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, (hipStream_t)stream);
 }
 
+// igemm_ct launch (transposed conv forward / backward-data as a ping-pong GEMM): one workgroup per budgeted CU, column blocks fastest
+static unsigned magic_floor32(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned)d); }
+static int run_ct(int mode, const void* a, int Ca, int N, int H, int W, const void* wp, long phase_stride, int ntiles_w, const float* bias,
+                  void* out, int outC, int Cn, const void* mask_src, hipStream_t st) {
+    IgCtParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = (const bf16_t*)a;
+    p.Ca = Ca;
+    p.nchunk = cdiv(Ca, 32);
+    p.N = N; p.H = H; p.W = W;
+    p.magic_hw = magic_floor32(H * W);
+    p.magic_w = magic_floor32(W);
+    p.wp = (const bf16_t*)wp;
+    p.wp_phase_stride = phase_stride;
+    p.ntiles_w = ntiles_w;
+    p.bias = bias;
+    p.out = (bf16_t*)out;
+    p.outC = outC;
+    p.Cn = Cn;
+    p.mask_src = (const bf16_t*)mask_src;
+    p.nnb = cdiv((mode == 0 ? 2 : 1) * Cn, 128);
+    p.ncob = (mode == 0 ? 2 : 1) * p.nnb;
+    const int ntile_m = cdiv(N * H * W, 256);
+    int cols = g_cu_budget.load() / p.ncob;   // workgroups per column block
+    if (cols < 1) cols = 1;
+    if (cols > ntile_m) cols = ntile_m;
+    HIP_CHECK_RET(igemm_ct_launch(mode, p, cols * p.ncob, st));
+    return RSU_OK;
+}
+
 extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
                                 rsu_stream_t stream) {
     if (!x || !packed_fwd || !y || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
@@ -593,6 +623,9 @@ extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const flo
     s.ptr = x; s.H = H; s.W = W; s.C = Cin; s.oy = 0; s.ox = 0;
     int seg[1] = {Cin};
     const long per = (long)(rsu_packed_bytes(1, Cout, seg, 1) / 2);
+    // RSU_CT_GEN=1: the 1-tap launches of igemm_fwd2 (one per output phase); default: the ping-pong GEMM of igemm_ct.hip
+    if (env_int("RSU_CT_GEN", 2) >= 2 && igemm_ct_supports(0, N, H, W, Cin, Cout) && (long)N * 4 * H * W * Cout * 2 < 0x7ffffff0L)
+        return run_ct(0, x, Cin, N, H, W, packed_fwd, per, rup(Cout, 128) / 16, bias, y, Cout, Cout, nullptr, (hipStream_t)stream);
     return run_fwd(&s, 1, packed_fwd, per, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, H, W, H, W, Cout, Cout, 1, 1, 1, 1, 0, 2 * H, 2 * W,
                    2, 4, 0, 0, (hipStream_t)stream);
 }
@@ -602,7 +635,8 @@ extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, voi
     if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2 || !(out_scale > 0.f)) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
-    const int rc = run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0,
+    const bool ct = env_int("RSU_CT_GEN", 2) >= 2 && igemm_ct_supports(1, N, H, W, Cout, Cin) && (long)N * 4 * H * W * Cout * 2 < 0x7ffffff0L;
+    const int rc = ct ? run_ct(1, dy, Cout, N, H, W, packed_bwd, 0, rup(Cin, 128) / 16, nullptr, dx, Cin, Cin, relu_src, (hipStream_t)stream) : run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0,
                            H, W, 1, 1, 0, 0, (hipStream_t)stream);
     if (rc != RSU_OK || out_scale == 1.f) return rc;
     // 1/keep of a dropout in front of the transposed conv: a separate pass over the (small) gradient tensor, training with

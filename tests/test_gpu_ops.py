@@ -288,7 +288,8 @@ def test_maxpool_fwd_and_junction_bwd(N, H, W, C):
 
 
 # ------------------------------------------------------------------------------------------- transposed conv
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 7, 9, 128, 64), (1, 14, 14, 64, 32), (1, 26, 24, 32, 16), (1, 28, 28, 256, 128)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 7, 9, 128, 64), (1, 14, 14, 64, 32), (1, 26, 24, 32, 16), (1, 28, 28, 256, 128),
+                                            (4, 28, 28, 1024, 512), (2, 52, 50, 96, 96), (1, 20, 21, 96, 160), (3, 33, 31, 72, 64)])
 def test_convT(N, H, W, Cin, Cout):
     rng = np.random.RandomState(Cin + H)
     x = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
