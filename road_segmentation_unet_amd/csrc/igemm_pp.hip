@@ -229,10 +229,12 @@ igemm_pp_kernel(const IgFwdParams p) {
         if (a_cl == 0) {
             if (a_started) {
                 if (pk + 1 < my_tiles) ++pk;  // behind the last tile the stream prefetches that tile again (valid memory, a slot nobody reads)
-                ptile = decode(pk);
+                if (!(DBG && (p.dbg & 256))) {   // (dbg bit 8: timing without the prefetch stream's tile change)
+                    ptile = decode(pk);
+                    setup_a(ptile, 0);
+                }
                 a_si = 0;
                 a_next_src = p.nchunk[0];
-                setup_a(ptile, 0);
             }
         } else if (a_cl == a_next_src) {
             ++a_si;
@@ -275,9 +277,21 @@ igemm_pp_kernel(const IgFwdParams p) {
     const int bias_base = dummy_base + 1024;
     const int stamp_base = bias_base + 512;
     int stamp_i = 0;
+    // STAMP builds also sum the cycles of named segments of the R intervals (reported in the last stamps of the wave)
+    unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_t0 = 0;
+    auto seg_begin = [&]() {
+        if constexpr (STAMP) seg_t0 = __builtin_amdgcn_s_memtime();
+    };
+    auto seg_end = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            seg_sum[k] += t - seg_t0;
+            seg_t0 = t;
+        }
+    };
     auto stamp = [&]() {
         if constexpr (STAMP) {
-            if (stamp_i < PP_NSTAMP - 2) {
+            if (stamp_i < PP_NSTAMP - 10) {
                 const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
                 if (lane == 0) *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + stamp_i) * 4) = t;
             }
@@ -329,56 +343,59 @@ igemm_pp_kernel(const IgFwdParams p) {
             // forward and backward-data without an AddN: everything on the packed bf16 result. ReLU is a packed int16 max against 0
             // (or, switched off, against the most negative int16: bf16 sign bit == int16 sign bit); the ReLU mask of backward-data
             // (relu_src > 0) is a packed 0 / 0xffff word ANDed onto it: max(x, 0) -> min(., 1) -> 0 - . (a positive NaN in relu_src
-            // counts as > 0 here; TensorFlow's ReluGrad lets nothing through there -- no finite activation is affected)
+            // counts as > 0 here; TensorFlow's ReluGrad lets nothing through there -- no finite activation is affected).
+            // One straight-line instance with and one without the mask, chosen by one wave-uniform branch up front: tested per store,
+            // the conditions (mask? inside? 1-bit masks?) cost the R interval that holds the epilogue ~2000 cycles in branches alone
+            // (tools/pp_stamps.py; the partner group, done with its MFMAs, waits at the barrier).
             typedef __attribute__((ext_vector_type(2))) short s2;
             const short fl = p.relu ? (short)0 : (short)-32768;
             const s2 floor2 = {fl, fl};
-            unsigned ones_pk = 0x00010001u;
-            asm volatile("" : "+v"(ones_pk));
-            u32x4 mk4[NST];
             unsigned voffs[NST];
-            unsigned mbits[NST];
-            const bool anybits = p.bits_out || p.bits_in;
-            const __amdgpu_buffer_rsrc_t brsrc =
-                __builtin_amdgcn_make_buffer_rsrc(p.bits_out ? (void*)p.bits_out : (void*)p.bits_in, 0, anybits ? (int)p.bits_bytes : 0, 0x00020000);
-            if (p.mask_src || !inside || anybits) {
+            if (inside) {   // (wave-uniform)
 #pragma unroll
-                for (int e = 0; e < NST; ++e) voffs[e] = inside ? ovoff[e / (CT / 2)] + (e % (CT / 2)) * 64 : out_voff(T, e);
+                for (int e = 0; e < NST; ++e) voffs[e] = ovoff[e / (CT / 2)] + (e % (CT / 2)) * 64;
+            } else {
+#pragma unroll
+                for (int e = 0; e < NST; ++e) voffs[e] = out_voff(T, e);
             }
-            if (p.mask_src) {  // every mask load of the tile is in flight before the first is used (the stage fragments are dead by now)
+            auto body = [&](const bool MASK) __attribute__((always_inline)) {   // (called with a constant: two straight-line copies)
+                unsigned ones_pk = 0x00010001u;
+                asm volatile("" : "+v"(ones_pk));
+                u32x4 mk4[NST];
+                if (MASK) {
+                    // every mask load of the tile in flight at once (the stage fragments are dead by now), then ONE wait. The loads are
+                    // asm like the stores: hipcc counts only the memory instructions it sees, and its own vmcnt(7 - e) in front of use e
+                    // would also wait for the e stores issued meanwhile -- store acknowledgements, thousands of cycles
 #pragma unroll
-                for (int e = 0; e < NST; ++e) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
-            }
-            if (p.bits_in) {  // 1-bit masks: one byte per store (a rejected lane's offset 0x80000000 >> 4 lies beyond bits_bytes: zeros)
+                    for (int e = 0; e < NST; ++e)
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(mk4[e]) : "v"(voffs[e]), "s"(mrsrc), "s"(sbase) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int e = 0; e < NST; ++e) mbits[e] = __builtin_amdgcn_raw_buffer_load_b8(brsrc, voffs[e] >> 4, sbase >> 4, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < NST; ++e) {
-                const int pt = e / (CT / 2), pp = e % (CT / 2);
-                u32x4 r;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
-                    const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
-                    r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
-                    r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                    for (int e = 0; e < NST; ++e) asm volatile("" : "+v"(mk4[e]));
                 }
-                if (p.mask_src) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
-                }
-                if (p.bits_in) {
+                for (int e = 0; e < NST; ++e) {
+                    const int pt = e / (CT / 2), pp = e % (CT / 2);
+                    u32x4 r;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] &= relu_mask_from_bits(mbits[e], i);
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
+                        const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
+                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                        r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                    }
+                    if (MASK) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
+                    }
+                    if (DBG && (p.dbg & 512)) {   // (dbg bit 9: timing of the epilogue without its stores)
+                        asm volatile("" ::"v"(r));
+                    } else {
+                        PP_STORE(r, voffs[e]);
+                    }
                 }
-                if (p.bits_out) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)relu_bits_pk(r, ones_pk), brsrc, voffs[e] >> 4, sbase >> 4, 0);
-                if (p.mask_src || !inside || anybits) {
-                    PP_STORE(r, voffs[e]);
-                } else {
-                    if (pp == 0) PP_STORE(r, ovoff[pt]); else PP_STORE64(r, ovoff[pt]);
-                }
-            }
+            };
+            if (p.mask_src) body(true); else body(false);
             return;
         }
         // every mask / accumulate load of the tile is requested before the first is used: one memory latency per tile, in registers
@@ -482,7 +499,8 @@ igemm_pp_kernel(const IgFwdParams p) {
         Tile ctile = decode(0);
         auto chunk = [&](auto parc, int gc) {
             constexpr int PAR = decltype(parc)::value;
-            if (c == 0) {
+            seg_begin();
+            if (c == 0 && !(DBG && (p.dbg & 16))) {   // (dbg bit 4: timing without the bias initialisation)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
@@ -494,11 +512,13 @@ igemm_pp_kernel(const IgFwdParams p) {
                     }
                 }
             }
+            seg_end(2);
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
             auto phase = [&](auto jc) {
                 constexpr int J = decltype(jc)::value;
                 // ================= R interval: the stage's fragment reads + bookkeeping for the stages ahead
                 bf16x8 fa[TPS][CT], fb[TPS][PT];
+                seg_begin();
                 if (!(DBG && (p.dbg & 32))) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
 #pragma unroll
                     for (int tl = 0; tl < TPS; ++tl) {
@@ -510,6 +530,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                             fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + boff[pt][tl] + (a_base + PAR * ABUF + J * ROWB));
                     }
                 }
+                seg_end(3);
                 // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
                 if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
                     if (!(DBG && (p.dbg & 2))) {
@@ -521,15 +542,17 @@ igemm_pp_kernel(const IgFwdParams p) {
                 if constexpr ((G ? WP1 : WP0) > 0) {
                     if (!(DBG && (p.dbg & 1))) issue_w(gconst, (J + 2) % NWB);
                 }
+                seg_end(4);
                 if constexpr (G == 1) {
                     // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
                     if (J == 0 && after_epi) {
-                        if (p.bits_out) RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + 2 * NST); else RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
+                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
                     } else {
                         RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
+                seg_end(5);
                 stamp();
                 bar();
                 stamp();
@@ -547,7 +570,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
                     if (J == 0 && after_epi) {
-                        if (p.bits_out) RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + 2 * NST); else RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
+                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
                     } else if (J == 2) {
                         RSU_WAIT_VMCNT(WP0);
                     } else {
@@ -564,10 +587,13 @@ igemm_pp_kernel(const IgFwdParams p) {
             phase(std::integral_constant<int, 2>{});
             if (c == nchunks - 1) {
                 // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
+                seg_begin();
                 if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
+                seg_end(0);
                 c = 0;
                 ++ck;
-                if (ck < my_tiles) ctile = decode(ck);
+                if (ck < my_tiles && !(DBG && (p.dbg & 64))) ctile = decode(ck);   // (dbg bit 6: timing without the tile decode)
+                seg_end(1);
             } else {
                 ++c;
             }
@@ -588,6 +614,7 @@ igemm_pp_kernel(const IgFwdParams p) {
             for (int i = lane; i < PP_NSTAMP; i += 64)
                 p.stamps[((long)blockIdx.x * NW + wave) * PP_NSTAMP + i] =
                     i == PP_NSTAMP - 2 ? dclk : (i == PP_NSTAMP - 1 ? drt :  // shader cycles and 100-MHz ticks of the main loop
+                    (i >= PP_NSTAMP - 10 && i < PP_NSTAMP - 2) ? (unsigned)seg_sum[i - (PP_NSTAMP - 10)] :
                     (i < stamp_i ? *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + i) * 4) : 0u));
         }
     }
@@ -654,6 +681,7 @@ bool igemm_pp_has(int cfg) { return cfg >= 0 && cfg < IGF2_NCFG && cfg != IGF2_C
 // planner's halo tile for strip width 2^lsw)
 bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
     if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
+    if (p.bits_out || p.bits_in) return false;   // the 1-bit ReLU masks (off by default) stay with igemm_fwd2
     const int TM = igemm_fwd2_cfg_info(cfg).TM;
     const int SW = 1 << p.lsw, TR = TM >> p.lsw;
     const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
@@ -671,10 +699,11 @@ bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
     if ((p.dbg & 128) && p.stamps) {  // diagnostic build with interval time stamps
+        if (cfg == IGF2_CFG_128x256 && (p.dbg & ~128)) return pp_launch_one<IGF2_CFG_128x256, true, true>(p, gx, st);
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, true>(p, gx, st);
         if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, true>(p, gx, st);
     }
-    if (p.dbg & 63) {  // timing experiments (RSU_FWD_DBG bits 0-5): the build that tests those bits
+    if (p.dbg & (63 | 64 | 256 | 512)) {  // timing experiments (RSU_FWD_DBG bits 0-6, 8): the build that tests those bits
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, false, true>(p, gx, st);
         if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, false, true>(p, gx, st);
     }
