@@ -120,17 +120,26 @@ igemm_pp_kernel(const IgFwdParams p) {
     const int nchunks = p.nchunk[0] + p.nchunk[1] + p.nchunk[2];
     const int GC = my_tiles * nchunks;  // chunks in this workgroup's stream
 
+    // this workgroup's tiles are tile0, tile0 + tstride, ...: (image, strip, row in strip) of the first one by division, then stepped --
+    // a run-time division costs ~20 vector instructions, and a vector instruction of an R interval waits for a gap between the
+    // partner wave's MFMAs (~17 cycles each, tools/pp_stamps.py)
     struct Tile { int n, x0, y0; };
-    auto decode = [&](int k) {
-        Tile T;
-        int t = tile0 + k * tstride;
-        T.n = t / tpi;
-        t -= T.n * tpi;
-        const int strip = t / p.g.tiles_per_strip;
-        T.x0 = strip * SW;
-        T.y0 = (t - strip * p.g.tiles_per_strip) * TR;
-        return T;
+    struct Pos { int n, strip, row; };
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto split = [&](int t) {
+        const int n = t / tpi, r = t - n * tpi;
+        const int strip = r / p.g.tiles_per_strip;
+        return Pos{sgpr(n), sgpr(strip), sgpr(r - strip * p.g.tiles_per_strip)};
     };
+    const Pos tstep = split(tstride);
+    auto advance = [&](Pos& q) {
+        q.row += tstep.row;
+        if (q.row >= p.g.tiles_per_strip) { q.row -= p.g.tiles_per_strip; ++q.strip; }
+        q.strip += tstep.strip;
+        if (q.strip >= p.g.nstrips) { q.strip -= p.g.nstrips; ++q.n; }
+        q.n += tstep.n;
+    };
+    auto tile_at = [&](const Pos& q) { return Tile{q.n, q.strip * SW, q.row * TR}; };
 
     // ---- workgroup constants (per lane)
     int boff[PT][KW];   // byte offset (inside a halo slot) of this lane's 16-byte fragment piece, per pixel fragment and kx
@@ -222,15 +231,19 @@ igemm_pp_kernel(const IgFwdParams p) {
             a_voff[q] = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
         }
     };
-    Tile ptile = decode(0);     // tile whose halo is being prefetched
+    Pos ppos = split(tile0);
+    Tile ptile = tile_at(ppos);     // tile whose halo is being prefetched
     int pk = 0;                 // index of ptile in this workgroup's list
     bool a_started = false;
     auto a_begin = [&]() {  // the next chunk of the stream: moves on to the next source / tile where one ends
         if (a_cl == 0) {
             if (a_started) {
-                if (pk + 1 < my_tiles) ++pk;  // behind the last tile the stream prefetches that tile again (valid memory, a slot nobody reads)
+                if (pk + 1 < my_tiles) {  // behind the last tile the stream prefetches that tile again (valid memory, a slot nobody reads)
+                    ++pk;
+                    advance(ppos);
+                }
                 if (!(DBG && (p.dbg & 256))) {   // (dbg bit 8: timing without the prefetch stream's tile change)
-                    ptile = decode(pk);
+                    ptile = tile_at(ppos);
                     setup_a(ptile, 0);
                 }
                 a_si = 0;
@@ -358,6 +371,7 @@ igemm_pp_kernel(const IgFwdParams p) {
 #pragma unroll
                 for (int e = 0; e < NST; ++e) voffs[e] = out_voff(T, e);
             }
+            seg_end(6);
             auto body = [&](const bool MASK) __attribute__((always_inline)) {   // (called with a constant: two straight-line copies)
                 unsigned ones_pk = 0x00010001u;
                 asm volatile("" : "+v"(ones_pk));
@@ -496,21 +510,21 @@ igemm_pp_kernel(const IgFwdParams p) {
         constexpr int G = decltype(gconst)::value;
         int c = 0;               // chunk inside the current tile
         int ck = 0;              // current tile
-        Tile ctile = decode(0);
+        Pos cpos = split(tile0);
+        Tile ctile = tile_at(cpos);
         auto chunk = [&](auto parc, int gc) {
             constexpr int PAR = decltype(parc)::value;
             seg_begin();
             if (c == 0 && !(DBG && (p.dbg & 16))) {   // (dbg bit 4: timing without the bias initialisation)
+                // every accumulator straight from the bias words in LDS: 16 LDS reads instead of 4 reads + 60 register moves (a vector
+                // instruction of an R interval waits for a gap between the partner's MFMAs; an LDS read does not). The reads land before
+                // the s_waitcnt lgkmcnt(0) that ends this R interval.
+                const unsigned baddr = (unsigned)(bias_base + (wco * (CT / 2) * 32 + 8 * g4) * 4);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const f32x4 bv = *(const __attribute__((address_space(3))) f32x4*)(lds + bias_base +
-                                                                                         ((wco * (CT / 2) + (ct >> 1)) * 32 + 8 * g4 + (ct & 1) * 4) * 4);
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        acc[ct][pt] = bv;
-                        asm volatile("" : "+v"(acc[ct][pt]));
-                    }
-                }
+                    for (int pt = 0; pt < PT; ++pt)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(acc[ct][pt]) : "v"(baddr), "n"(((ct >> 1) * 32 + (ct & 1) * 4) * 4) : "memory");
             }
             seg_end(2);
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
@@ -592,7 +606,10 @@ igemm_pp_kernel(const IgFwdParams p) {
                 seg_end(0);
                 c = 0;
                 ++ck;
-                if (ck < my_tiles && !(DBG && (p.dbg & 64))) ctile = decode(ck);   // (dbg bit 6: timing without the tile decode)
+                if (ck < my_tiles && !(DBG && (p.dbg & 64))) {   // (dbg bit 6: timing without the tile change)
+                    advance(cpos);
+                    ctile = tile_at(cpos);
+                }
                 seg_end(1);
             } else {
                 ++c;

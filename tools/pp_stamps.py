@@ -63,10 +63,10 @@ ok = rt > 0
 print("in-kernel clock (shader cycles / 100-MHz ticks, per workgroup): median %.3f GHz, min %.3f, max %.3f; loop length median %.1f us"
       % (np.median(clk[ok] / rt[ok]) * 0.1, (clk[ok] / rt[ok]).min() * 0.1, (clk[ok] / rt[ok]).max() * 0.1, np.median(rt[ok]) * 0.01))
 seg = s[:, :, NST - 10:NST - 2].astype(np.float64)
-names = ["epilogue", "tile decode", "bias init", "fragment reads (issue)", "prefetch issues", "waits (vmcnt, lgkmcnt)"]
+names = ["epilogue (convert + store)", "tile decode", "bias init", "fragment reads (issue)", "prefetch issues", "waits (vmcnt, lgkmcnt)", "epilogue (addresses)"]
 for wv in (0, 4):
     print("wave %d, cycles per workgroup in R-interval segments (median over workgroups): " % wv +
-          ", ".join("%s %.0f" % (names[k], np.median(seg[ok, wv, k])) for k in range(6)) + "; loop %.0f" % np.median(clk[ok]))
+          ", ".join("%s %.0f" % (names[k], np.median(seg[ok, wv, k])) for k in range(7)) + "; loop %.0f" % np.median(clk[ok]))
 s[:, :, NST - 10:] = 0
 # stamps per phase of a wave: [end of R work] barrier [start of M] ... [end of M issue] barrier [start of next R]
 for blk in (0, 100):
