@@ -30,11 +30,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 
 // ---- packed ReLU mask: 0xffff in each half of the result where the bf16 half of m is > 0 (sign clear, not zero), else 0:
-// max(m, 0) -> min(., 1) -> 0 - . on packed int16 (bf16 sign bit == int16 sign bit). Three VALU instructions per two elements; as
-// plain vector code hipcc turns the same arithmetic into two compares, two selects and a permute. A positive NaN counts as > 0.
-__device__ __forceinline__ unsigned pos_mask_pk_bf16(unsigned m, unsigned ones_pk /* 0x00010001 in a VGPR */) {
+// 0 - m with saturation (so that m = 0x8000, minus zero, becomes +32767), then an arithmetic shift by 15 spreads the sign: negative
+// exactly where m was positive (bf16 sign bit == int16 sign bit). Two VALU instructions per two elements; as plain vector code hipcc
+// turns the same test into two compares, two selects and a permute. A positive NaN counts as > 0. (`ones_pk` is no longer used.)
+__device__ __forceinline__ unsigned pos_mask_pk_bf16(unsigned m, unsigned /*ones_pk*/ = 0) {
     unsigned t;
-    asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_i16 %0, %0, %2\n\tv_pk_sub_i16 %0, 0, %0" : "=&v"(t) : "v"(m), "v"(ones_pk));
+    asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(t) : "v"(m));   // (op_sel_hi: both halves shift by the constant's LOW half)
     return t;
 }
 
