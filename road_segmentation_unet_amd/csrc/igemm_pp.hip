@@ -601,9 +601,17 @@ igemm_pp_kernel(const IgFwdParams p) {
             phase(std::integral_constant<int, 2>{});
             if (c == nchunks - 1) {
                 // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
+                // Tile boundary: both groups store the finished tile in ONE interval of their own, with no MFMAs beside it. A vector
+                // instruction next to the partner's MFMA stream waits ~17 cycles for an issue gap (tools/pp_stamps.py): folded into the
+                // next R interval, each group's epilogue made that interval ~2500 cycles longer than the partner's MFMAs, twice per
+                // tile. Now G0 sits out G1's last MFMA interval, both run their epilogues together at the full issue rate, and G1 sits
+                // out G0's first R interval of the next tile: two short extra intervals instead of two long ones.
+                if constexpr (G == 0) bar();
                 seg_begin();
                 if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
                 seg_end(0);
+                bar();
+                if constexpr (G == 1) bar();
                 c = 0;
                 ++ck;
                 if (ck < my_tiles && !(DBG && (p.dbg & 64))) {   // (dbg bit 6: timing without the tile change)
