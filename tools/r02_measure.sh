@@ -10,6 +10,10 @@ rm -rf $OUT; mkdir -p $OUT
 export RSU_AUTOTUNE_FILE=$OUT/autotune.json
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
+# the profiled runs keep every launch on ONE stream (RSU_WGRAD_STREAM=0): in the default schedule a backward-data and a weight-gradient
+# kernel share the chip and a trace would charge each with the time it spent beside the other. bench.py's roofline figure comes from
+# the same single-stream plan (its instrumented pass), so the per-kernel averages of the two agree.
+export RSU_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r02 -- python3 $REPO/bench.py --steps 10 --warmup 2 --no_cpu_baseline --sustain_seconds 0 > $OUT/prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc -o rd -- python3 $REPO/bench.py --steps 3 --warmup 1 --no_cpu_baseline --sustain_seconds 0 > $OUT/log_rd.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc -o wr -- python3 $REPO/bench.py --steps 3 --warmup 1 --no_cpu_baseline --sustain_seconds 0 > $OUT/log_wr.txt 2>&1
