@@ -55,7 +55,12 @@ typedef struct {
 const char* rsu_version(void);
 int rsu_last_hip_error(void);
 /* Compute units the persistent conv launches plan for (32..256, default 256 = the whole MI355X). New here (the reference is
- * single-device): a data-parallel host may leave some CUs to the RCCL channel workgroups of an overlapped gradient all-reduce. */
+ * single-device). The value is read when a launch is planned, so a single-threaded host may change it from launch to launch:
+ * a data-parallel host leaves some CUs to the RCCL channel workgroups of an overlapped gradient all-reduce, and the Python host
+ * (unet.py, RSU_SPLIT_CHIP) plans the backward-data launches of its main stream and the weight-gradient launches of its side
+ * stream for disjoint halves of the chip, so that one kernel of each kind is resident at a time. For the weight gradients the
+ * budget sets the number of partial sums per output tile: it changes their summation order (results agree to fp32 rounding),
+ * for every other launch it only changes speed. */
 int rsu_set_cu_budget(int ncu);
 int rsu_get_cu_budget(void);
 /* Tile-shape choice of the conv launches by measurement (default on; RSU_AUTOTUNE=0 in the environment also disables it): the
