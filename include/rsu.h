@@ -192,6 +192,10 @@ int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_st
  * x bf16 [N][H][W][C] -> y [N][H/2][W/2][C] */
 int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key,
                        rsu_stream_t stream);
+/* ... and, for training, a code tensor for the gradient junction below (H, W even; code [N][H/2][W/2][C] bytes, may be NULL):
+ * per pooled element bits 0-3 = (window element 2*dy+dx > 0), bits 4-5 = the window's first maximum in row-major order. */
+int rsu_maxpool2x2_fwd_code(const void* x, void* y, void* code, int N, int H, int W, int C, float keep, unsigned key,
+                            rsu_stream_t stream);
 /* Gradient junction at an encoder output y_act (ReLU output, bf16 [N][H][W][C]):
  *   g = MaxPoolGrad(y_act, dropout_grad(dpool))  (dpool bf16 [N][H/2][W/2][C], may be NULL; (keep, key) as in
  *                                             rsu_maxpool2x2_fwd: dpool is the gradient of the DROPPED pooled tensor)
@@ -201,6 +205,10 @@ int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float
  * MaxPoolGrad routes to the first maximum of the window in row-major order. */
 int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W,
                            int C, int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream);
+/* The same junction from the code tensor of rsu_maxpool2x2_fwd_code instead of the activation (y_act may then be NULL): one
+ * byte per pooled element instead of four bf16 activations, the same bits. */
+int rsu_pool_skip_relu_bwd_code(const void* y_act, const void* code, const void* dpool, const void* dskip, void* dz, int N,
+                                int H, int W, int C, int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream);
 /* unet.py:64-65 dropout in front of a transposed conv: y = x / keep * floor(keep + U), bf16 [n] -> bf16 [n] (n % 8 == 0).
  * Its backward is fused into rsu_convT2x2_bwd_data: pass y as relu_src (y > 0 <=> x > 0 and kept) and out_scale = 1/keep. */
 int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsigned key, rsu_stream_t stream);

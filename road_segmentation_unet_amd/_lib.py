@@ -71,6 +71,8 @@ SIGNATURES = {
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
     "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),
+    "rsu_maxpool2x2_fwd_code": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),
+    "rsu_pool_skip_relu_bwd_code": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_pool_skip_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),

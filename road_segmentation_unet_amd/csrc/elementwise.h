@@ -14,8 +14,8 @@ hipError_t ew_color_adjust(const float* x, const float* w, const float* b, void*
 hipError_t ew_scale_bf16(void* x, long n, float s, hipStream_t st);
 hipError_t ew_dropout(const void* x, void* y, long n, float keep, unsigned key, hipStream_t st);
 hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int Cout, hipStream_t st);
-hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st);
-hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws,
+hipError_t ew_maxpool_fwd(const void* x, void* y, void* code, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st);
+hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* code, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs, int Ws,
                                  float keep, unsigned key, hipStream_t st);
 int ew_colsum_blocks(long npix, int C);
 hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hipStream_t st);

@@ -87,7 +87,11 @@ __global__ void k_scatter_first_grads(const float* __restrict__ tmp, float* __re
 // ---------------------------------------------------------------------------------------------
 // 2x2 max pool forward
 // ---------------------------------------------------------------------------------------------
-__global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, float keep, unsigned key) {
+// `code` (optional, [N][H/2][W/2][C] bytes): per pooled element, bits 0-3 = (window element k > 0) for k = 2*dy + dx, bits 4-5 =
+// the window's first maximum in row-major order -- everything the MaxPoolGrad + ReluGrad junction needs from the activation
+// (k_pool_skip_relu_bwd then reads one byte per pooled element instead of four bf16 activations)
+__global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ code, int N, int H, int W, int C,
+                              float keep, unsigned key) {
     const float inv = keep < 1.f ? 1.f / keep : 1.f;
     const int Ho = H >> 1, Wo = W >> 1, ncg = C >> 3;
     const long total = (long)N * Ho * Wo * ncg;
@@ -103,9 +107,23 @@ __global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__
         unpack8(*(const u32x4*)(p + C), b);
         unpack8(*(const u32x4*)(p + (long)W * C), c);
         unpack8(*(const u32x4*)(p + (long)W * C + C), d);
+        const long oidx = ((long)(n * Ho + oy) * Wo + ox) * C + cg * 8;
+        if (code) {
+            unsigned cw[2] = {0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int best = 0;
+                float m = a[i];
+                if (b[i] > m) { m = b[i]; best = 1; }
+                if (c[i] > m) { m = c[i]; best = 2; }
+                if (d[i] > m) { m = d[i]; best = 3; }
+                const unsigned byte = (a[i] > 0.f ? 1u : 0u) | (b[i] > 0.f ? 2u : 0u) | (c[i] > 0.f ? 4u : 0u) | (d[i] > 0.f ? 8u : 0u) | ((unsigned)best << 4);
+                cw[i >> 2] |= byte << (8 * (i & 3));
+            }
+            *(uint2*)(code + oidx) = make_uint2(cw[0], cw[1]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = fmaxf(fmaxf(a[i], b[i]), fmaxf(c[i], d[i]));
-        const long oidx = ((long)(n * Ho + oy) * Wo + ox) * C + cg * 8;
         if (keep < 1.f) {  // dropout of the next level's input (unet.py:29-30), fused
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] *= drop_keep(key, (unsigned)(oidx + i), keep) * inv;
@@ -118,7 +136,7 @@ __global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__
 // gradient junction at an encoder output: MaxPoolGrad + zero-padded skip gradient + ReluGrad.
 // One thread = 8 channels of one 2x2 window.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const bf16_t* __restrict__ dpool,
+__global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const unsigned char* __restrict__ code, const bf16_t* __restrict__ dpool,
                                      const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dz, int N, int H, int W, int C,
                                      int Hs, int Ws, float keep, unsigned key) {
     const float inv = keep < 1.f ? 1.f / keep : 1.f;
@@ -134,11 +152,25 @@ __global__ void k_pool_skip_relu_bwd(const bf16_t* __restrict__ yact, const bf16
         const int wy = (int)(r % Hw), n = (int)(r / Hw);
         float v[4][8], g[4][8];
         bool inb[4];
+        // with a code tensor (H, W even: every window is whole) the activation is not read: v[k] = 1 where it was > 0, and 2 at the
+        // window's first maximum -- the same comparisons below then pick the same elements
+        unsigned cw[2] = {0u, 0u};
+        if (code) {
+            const uint2 c2 = *(const uint2*)(code + ((long)(n * Hp + wy) * Wp + wx) * C + cg * 8);
+            cw[0] = c2.x;
+            cw[1] = c2.y;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
             inb[k] = (yy < H) && (xx < W);
-            if (inb[k]) {
+            if (code) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned byte = (cw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    v[k][i] = ((byte >> k) & 1u) ? ((int)(byte >> 4) == k ? 2.f : 1.f) : ((int)(byte >> 4) == k ? 0.f : -1.f);
+                }
+            } else if (inb[k]) {
                 unpack8(*(const u32x4*)(yact + ((long)(n * H + yy) * W + xx) * C + cg * 8), v[k]);
             } else {
 #pragma unroll
@@ -689,15 +721,17 @@ hipError_t ew_scatter_first_grads(const float* tmp, float* dw1, float* gxc, int 
     hipLaunchKernelGGL(k_scatter_first_grads, dim3((9 * 12 * Cout + 255) / 256), dim3(256), 0, st, tmp, dw1, gxc, Cout);
     return hipGetLastError();
 }
-hipError_t ew_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st) {
+hipError_t ew_maxpool_fwd(const void* x, void* y, void* code, int N, int H, int W, int C, float keep, unsigned key, hipStream_t st) {
     const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, keep, key);
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)code, N, H, W, C, keep,
+                       key);
     return hipGetLastError();
 }
-hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C, int Hs,
-                                 int Ws, float keep, unsigned key, hipStream_t st) {
+hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* code, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C,
+                                 int Hs, int Ws, float keep, unsigned key, hipStream_t st) {
     const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
-    hipLaunchKernelGGL(k_pool_skip_relu_bwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)yact, (const bf16_t*)dpool,
+    hipLaunchKernelGGL(k_pool_skip_relu_bwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)yact, (const unsigned char*)code,
+                       (const bf16_t*)dpool,
                        (const bf16_t*)dskip, (bf16_t*)dz, N, H, W, C, Hs, Ws, keep, key);
     return hipGetLastError();
 }

@@ -791,18 +791,29 @@ extern "C" int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, in
 // ---------------------------------------------------------------------------------------------
 // pool, head, optimizer, tiler
 // ---------------------------------------------------------------------------------------------
-extern "C" int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, rsu_stream_t stream) {
+extern "C" int rsu_maxpool2x2_fwd_code(const void* x, void* y, void* code, int N, int H, int W, int C, float keep, unsigned key,
+                                       rsu_stream_t stream) {
     if (!x || !y || C % 8 || H < 2 || W < 2 || !keep_ok(keep)) return RSU_EINVAL;
+    if (code && ((H | W) & 1)) return RSU_EINVAL;
     if (keep < 1.f && (long)N * (H / 2) * (W / 2) * C > 0xffffffffL) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_maxpool_fwd(x, y, N, H, W, C, keep, key, (hipStream_t)stream));
+    HIP_CHECK_RET(ew_maxpool_fwd(x, y, code, N, H, W, C, keep, key, (hipStream_t)stream));
+    return RSU_OK;
+}
+extern "C" int rsu_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, float keep, unsigned key, rsu_stream_t stream) {
+    return rsu_maxpool2x2_fwd_code(x, y, nullptr, N, H, W, C, keep, key, stream);
+}
+extern "C" int rsu_pool_skip_relu_bwd_code(const void* y_act, const void* code, const void* dpool, const void* dskip, void* dz, int N, int H,
+                                           int W, int C, int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream) {
+    if ((!y_act && !code) || !dz || C % 8 || !keep_ok(keep)) return RSU_EINVAL;
+    if (code && (((H | W) & 1) || H < 2 || W < 2)) return RSU_EINVAL;   // the code tensor describes whole 2x2 windows
+    if (dskip && (Hs > H || Ws > W || Hs < 1 || Ws < 1)) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_pool_skip_relu_bwd(y_act, code, dpool, dskip, dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, keep, key, (hipStream_t)stream));
     return RSU_OK;
 }
 extern "C" int rsu_pool_skip_relu_bwd(const void* y_act, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C,
                                       int Hs, int Ws, float keep, unsigned key, rsu_stream_t stream) {
-    if (!y_act || !dz || C % 8 || !keep_ok(keep)) return RSU_EINVAL;
-    if (dskip && (Hs > H || Ws > W || Hs < 1 || Ws < 1)) return RSU_EINVAL;
-    HIP_CHECK_RET(ew_pool_skip_relu_bwd(y_act, dpool, dskip, dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, keep, key, (hipStream_t)stream));
-    return RSU_OK;
+    if (!y_act) return RSU_EINVAL;
+    return rsu_pool_skip_relu_bwd_code(y_act, nullptr, dpool, dskip, dz, N, H, W, C, Hs, Ws, keep, key, stream);
 }
 static bool head_c_ok(int C) { return C >= 8 && C <= 512 && (C % 8) == 0 && ((C / 8) & (C / 8 - 1)) == 0; }
 extern "C" int rsu_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate,

@@ -115,6 +115,7 @@ class UNet:
             self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
             self.wstream = self.wstreams[0]
         self.bits, self._bits_of = {}, {}
+        self.pool_code = {}
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
@@ -239,6 +240,11 @@ class UNet:
                             self.bits[k] = torch.zeros(nb, dtype=torch.uint8, device=dev)
             self._bits_of = {self.act[k].data_ptr(): b for k, b in self.bits.items()}
             self.gfirst = torch.zeros((2, 9, 12, self.root), dtype=torch.float32, device=dev)  # gx of conv1 / atrous_conv1 (rsu.h)
+            # code bytes of the max-pools (argmax + ReLU bits per pooled element, rsu_maxpool2x2_fwd_code): the gradient junction of a
+            # level reads them instead of the level's conv2 activation. RSU_POOL_CODE=0: it reads the activation (same bits)
+            if os.environ.get("RSU_POOL_CODE", "1") == "1":
+                for i in range(L - 1):
+                    self.pool_code[i] = torch.zeros(self.act["pool_%d" % i].shape, dtype=torch.uint8, device=dev)
 
     def _conv_sources_c(self, name, shape):
         """channel counts of the concat sources feeding conv `name` (decoder conv1: [skip,(dil skip),up], unet.py:79/85)"""
@@ -435,7 +441,8 @@ class UNet:
             self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
             if not last:
                 c2 = a["c2_%d" % i]
-                call("rsu_maxpool2x2_fwd", _ptr(c2), _ptr(a["pool_%d" % i]), B, h - 4, h - 4, c2.shape[3], keep, self.dropout_key(i + 1), st)
+                call("rsu_maxpool2x2_fwd_code", _ptr(c2), _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 4, h - 4, c2.shape[3], keep,
+                     self.dropout_key(i + 1), st)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
         if self.dilated:
@@ -540,7 +547,7 @@ class UNet:
             if i < L - 1:
                 dec = L - 2 - i
                 hs = a["up_%d" % dec].shape[1]
-                call("rsu_pool_skip_relu_bwd", _ptr(c2), _ptr(g["pool_%d" % i]), _ptr(g["skip_%d" % dec]), _ptr(dz2), B, h - 4, h - 4, nf, hs, hs,
+                call("rsu_pool_skip_relu_bwd_code", _ptr(c2), _ptr(self.pool_code.get(i)), _ptr(g["pool_%d" % i]), _ptr(g["skip_%d" % dec]), _ptr(dz2), B, h - 4, h - 4, nf, hs, hs,
                      keep, self.dropout_key(i + 1), st)
             self._wgrad("conv_%d/conv2" % i, [(c1, h - 2)], dz2, h - 4)
             self._bwd_data("conv_%d/conv2" % i, dz2, dz1, h - 2, relu_src=c1)

@@ -285,6 +285,15 @@ def test_maxpool_fwd_and_junction_bwd(N, H, W, C):
             g += U.center_pad_like(dskip, x.shape)
         ref = U.relu_bwd(x, g)
         hu.assert_bf16_close(hu.host(dz), ref, "pool_skip_relu_bwd pool=%d skip=%d" % (use_pool, use_skip))
+        if H % 2 == 0 and W % 2 == 0:
+            # the same junction from the pool's code bytes (argmax + ReLU bits) instead of the activation: the same bits
+            code = torch.full((N, H // 2, W // 2, C), 255, dtype=torch.uint8, device=hu.DEV)
+            y2 = torch.zeros_like(y)
+            call("rsu_maxpool2x2_fwd_code", hu.ptr(xd), hu.ptr(y2), hu.ptr(code), N, H, W, C, kp, key, hu.stream())
+            dz2 = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+            call("rsu_pool_skip_relu_bwd_code", None, hu.ptr(code), hu.ptr(dpd) if use_pool else None,
+                 hu.ptr(dsd) if use_skip else None, hu.ptr(dz2), N, H, W, C, Hs, Ws, kp, key, hu.stream())
+            assert torch.equal(dz.view(torch.int16), dz2.view(torch.int16)), "code-byte junction differs"
 
 
 # ------------------------------------------------------------------------------------------- transposed conv
