@@ -113,4 +113,6 @@ hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int gri
                               hipStream_t st);
 // ping-pong wave groups (igemm_wgpp.hip): the 128x64 shape of the 3x3 stride-1 weight gradient, same slabs and bits as igemm_wgrad
 bool igemm_wgpp_supports(int cfg, int ntap, const IgWgradParams& p);
+bool igemm_wgp64_supports(int cfg, int ntap, const IgWgradParams& p);
+hipError_t igemm_wgp64_launch(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st);
 hipError_t igemm_wgpp_launch(const IgWgradParams& p, int grid_x, int grid_y, int grid_z, hipStream_t st);

@@ -362,6 +362,319 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// igemm_wgp64: the 64 x 64 shape (layers with 64 gradient channels: one workgroup holds the whole 9 x 64 x 64 block of dW for its
+// pixel split) as a ping-pong. Both groups read the same 64 F channels; the NINE TAPS are dealt over them: G0 = waves 0-3 taps 0-4,
+// G1 = waves 4-7 taps 5-8 and the bias sums; wave w of a group owns S channels 16*(w&3).. as in igemm_wgpp. A phase is TWO 32-pixel
+// k-steps (36 / 32 transposed reads, 40 / 34 MFMAs per wave), a pixel tile two phases. Staging: ring of THREE slots ([F 16 KiB][S
+// halo]), tile t in slot t % 3; the 2 + NSW pieces per wave of tile t+2 are issued in the R intervals of tile t, tile t+1 is waited
+// for (counted vmcnt: tile t+2's pieces stay in flight) at the end of G1's last R interval / behind G0's last MFMAs of tile t. The
+// stream never ends: behind the last tile it stages that tile again into a slot nobody reads, so the counts always hold.
+// The summation order differs from igemm_wgrad's 64x64 shape (which split the k-steps over its wave groups): results agree to fp32
+// rounding, not bit for bit.
+template <int LSW>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgp64_kernel(const IgWgradParams p) {
+    constexpr int NW = 8, KW = 3, TMK = 128, CFT = 4;
+    constexpr int SW = 1 << LSW, TR = TMK >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8;
+    constexpr int NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    constexpr int NSW = ((NPIX + 7) / 8 + 7) / 8;
+    constexpr int NFW = 2;                                 // F pieces per wave per tile: 128 px x 1 plane / 8 px / 8 waves
+    constexpr int NP = NFW + NSW;
+    constexpr int FBUF = TMK * 128, SBUF = NSW * NW * 1024, SLOT = FBUF + SBUF, NSLOT = 3;
+    static_assert(NSLOT * SLOT <= 160 * 1024, "staging budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wcs = wave & 3;
+    const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
+    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y);
+    const int tpi = p.g.nstrips * p.g.tiles_per_strip;
+    auto sgpr = [](auto v) { return __builtin_amdgcn_readfirstlane(v); };
+
+    // ---- per-lane LDS read offsets inside the CURRENT slot (they move by SLOT / -2 SLOT per tile)
+    int fo[2][CFT], so[2][KW];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int ml = rd * 16 + 4 * g4 + q4;
+        const int ch = 4 * p4;
+        const int f0 = ml * 128 + ((((ch & 63) >> 4) ^ ((ml >> 1) & 3)) << 5) + (ch & 15) * 2;
+#pragma unroll
+        for (int ct = 0; ct < CFT; ++ct) fo[rd][ct] = f0 ^ (((ct + wcs) & 3) << 5);   // F tiles numbered from the wave's own (bias tile = column 0)
+        const int ty = ml >> LSW, tx = ml & (SW - 1);
+        const int hp0 = ty * CW + tx;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int hp = hp0 + kx;
+            const int chs = wcs * 16 + 4 * p4;
+            so[rd][kx] = FBUF + hp * 128 + ((((chs >> 4) ^ ((hp >> 1) & 3))) << 5) + (chs & 15) * 2;
+        }
+    }
+    auto sdelta = [](int k) constexpr {
+        const int m0 = k * 32;
+        return ((m0 >> LSW) * CW + (m0 & (SW - 1))) * 128;
+    };
+    // ---- staging (scalar addressing as in igemm_wgpp)
+    const int l8 = lane >> 3;
+    const int cswz8 = ((lane & 7) ^ (((l8 >> 1) & 3) << 1)) * 8;
+    unsigned lvF = (unsigned)((l8 * p.Cf + cswz8) * 2), lvS = (unsigned)((l8 * p.S.C + cswz8) * 2);
+    asm volatile("" : "+v"(lvF), "+v"(lvS));
+    const int limcS = p.S.C - csb * 64, limcF = p.Cf - cfb * 64;
+    const int wty = (wave * 8) >> LSW, wtx0 = (wave * 8) & (SW - 1);
+    const unsigned rowF = sgpr((unsigned)(p.Wf * p.Cf * 2) * (64 >> LSW));
+    const unsigned wbF = sgpr((unsigned)((wty * p.Wf + wtx0) * p.Cf * 2));
+    unsigned wbS[NSW];
+#pragma unroll
+    for (int q = 0; q < NSW; ++q) {
+        const int hp0 = q * 64 + wave * 8, rr = hp0 / CW, cc0 = hp0 - rr * CW;
+        wbS[q] = sgpr((unsigned)((rr * p.S.W + cc0) * p.S.C * 2));
+    }
+    constexpr int HROWS = (NPIX - 1) / CW + 1;
+    struct Tile { unsigned bF, bS; int insF, insS, ry, rx; };
+    struct Pos { int n, strip, row; };
+    auto split = [&](int t) {
+        const int n = t / tpi, r = t - n * tpi;
+        const int strip = r / p.g.tiles_per_strip;
+        return Pos{sgpr(n), sgpr(strip), sgpr(r - strip * p.g.tiles_per_strip)};
+    };
+    const Pos step = split(p.nsplit);
+    auto advance = [&](Pos& q) {
+        q.row += step.row;
+        if (q.row >= p.g.tiles_per_strip) { q.row -= p.g.tiles_per_strip; ++q.strip; }
+        q.strip += step.strip;
+        if (q.strip >= p.g.nstrips) { q.strip -= p.g.nstrips; ++q.n; }
+        q.n += step.n;
+    };
+    auto decode = [&](const Pos& q) {
+        Tile T;
+        const int x0 = q.strip * SW, y0 = q.row * TR;
+        T.bF = sgpr((unsigned)((((long)(q.n * p.Hf + y0) * p.Wf + x0) * p.Cf + cfb * 64) * 2) + wbF);
+        T.bS = sgpr((unsigned)((((long)(q.n * p.S.H + y0 + p.S.oy) * p.S.W + x0 + p.S.ox) * p.S.C + csb * 64) * 2));
+        T.ry = sgpr(p.Hf - y0);
+        T.rx = sgpr(p.Wf - x0);
+        T.insF = (int)(TR <= T.ry) & (int)(SW <= T.rx) & (int)(limcF >= 64);
+        T.insS = (int)(HROWS <= T.ry + 2) & (int)(CW <= T.rx + 2) & (int)(limcS >= 64);
+        return T;
+    };
+    auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
+    auto issue_piece = [&](const Tile& T, auto ic, int buf) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I < NFW) {
+            const __amdgpu_buffer_rsrc_t rf = mk(p.F);
+            const unsigned soff = T.bF + I * rowF;
+            unsigned vo = lvF;
+            if (!T.insF) {
+                const int ty = wty + I * (64 >> LSW);
+                const int limx = ty < T.ry ? T.rx - wtx0 : 0;
+                vo = (l8 < limx && cswz8 < limcF) ? lvF : RSU_SENT;
+            }
+            bdma16w(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
+        } else if constexpr (I < NP) {
+            constexpr int Q = I - NFW;
+            const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
+            const unsigned soff = T.bS + wbS[Q];
+            constexpr bool whole = NPIX >= (Q + 1) * 64;
+            unsigned vo = lvS;
+            if (!whole || !T.insS) {
+                const int hp0 = Q * 64 + wave * 8, rr = hp0 / CW, cc0 = hp0 - rr * CW;
+                const int limx = (hp0 < NPIX && rr < T.ry + 2) ? T.rx + 2 - cc0 : 0;
+                vo = (l8 < limx && cswz8 < limcS) ? lvS : RSU_SENT;
+            }
+            bdma16w(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
+        }
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto tr_read = [&](int off) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(lds + off));
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    auto issue_half = [&](const Tile& T, auto hc, int buf) {   // the first / second half of a tile's pieces of this wave
+        constexpr int H = decltype(hc)::value;
+        if constexpr (H == 0) {
+            issue_piece(T, I0{}, buf);
+            issue_piece(T, I1{}, buf);
+            issue_piece(T, I2{}, buf);
+        } else {
+            issue_piece(T, I3{}, buf);
+            issue_piece(T, I4{}, buf);
+            issue_piece(T, I5{}, buf);
+            issue_piece(T, I6{}, buf);
+        }
+    };
+
+    // ---- prefetch stream: tile index (in this split) and position of the tile staged next
+    const int ntile_mine = (p.ntiles_total - z + p.nsplit - 1) / p.nsplit;   // tiles z, z + nsplit, ...
+    Pos ppos = split(z);
+    int pf_k = 0;        // index (in this workgroup's list) of the tile the stream stages next; stays at the last tile
+    int pf_slot = 0;
+    Tile PT = decode(ppos);
+    auto pf_next = [&]() {
+        if (pf_k + 1 < ntile_mine) {
+            ++pf_k;
+            advance(ppos);
+            PT = decode(ppos);
+        }
+        pf_slot = pf_slot == NSLOT - 1 ? 0 : pf_slot + 1;
+    };
+    // prologue: tiles 0 and 1 (or tile 0 twice), all of them
+    issue_half(PT, I0{}, 0);
+    issue_half(PT, I1{}, 0);
+    pf_next();
+    issue_half(PT, I0{}, 1);
+    issue_half(PT, I1{}, 1);
+    pf_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (grp) bar();
+
+    const bool do_bias = (p.bslab != nullptr) && (csb == 0);
+    auto run = [&](auto gconst) {
+        constexpr int G = decltype(gconst)::value;
+        constexpr int T0 = G ? 5 : 0, NT = G ? 4 : 5;
+        f32x4 acc[NT][CFT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int a = 0; a < CFT; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+        int cur = 0;   // slot of the current tile
+        for (int k = 0; k < ntile_mine; ++k) {
+            auto phase = [&](auto phc) {
+                constexpr int PH = decltype(phc)::value;
+                // ================= R interval: the fragments of k-steps 2 PH and 2 PH + 1, half of the pieces of tile k + 2
+                bf16x8 fa[2][CFT], sv[2][NT];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int K = 2 * PH + ks;
+#pragma unroll
+                    for (int ct = 0; ct < CFT; ++ct) {
+                        const bf16x4 lo = tr_read(fo[0][ct] + K * 32 * 128), hi = tr_read(fo[1][ct] + K * 32 * 128);
+                        fa[ks][ct] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int tap = T0 + t, ky = tap / KW, kx = tap - ky * KW;
+                        const int off = ky * CW * 128 + sdelta(K);
+                        const bf16x4 lo = tr_read(so[0][kx] + off), hi = tr_read(so[1][kx] + off);
+                        sv[ks][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                issue_half(PT, phc, pf_slot);
+                if constexpr (PH == 1) {
+                    pf_next();
+                    // the reads above carry the old addresses: move them to the next tile's slot
+                    const int mv = cur == NSLOT - 1 ? -(NSLOT - 1) * SLOT : SLOT;
+                    cur = cur == NSLOT - 1 ? 0 : cur + 1;
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) {
+                            fo[rd][ct] += mv;
+                            asm volatile("" : "+v"(fo[rd][ct]));
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < KW; ++kx) {
+                            so[rd][kx] += mv;
+                            asm volatile("" : "+v"(so[rd][kx]));
+                        }
+                    }
+                    if constexpr (G == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // tile k + 1 has landed (k + 2 may be in flight)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bar();
+                // ================= M interval
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int ct = 0; ct < CFT; ++ct) mfma_bf16_inplace(acc[t][ct], fa[ks][ct], sv[ks][t]);
+                    if (G == 1 && do_bias) {
+                        unsigned o1 = 0x3f803f80u;
+                        asm volatile("" : "+v"(o1));
+                        const u32x4 o4 = {o1, o1, o1, o1};
+                        bf16x8 ones = __builtin_bit_cast(bf16x8, o4);
+                        asm volatile("s_nop 3" : "+v"(ones));
+                        mfma_bf16_inplace(accb, fa[ks][0], ones);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PH == 1 && G == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                bar();
+            };
+            phase(I0{});
+            phase(I1{});
+        }
+        mfma_results_fence();
+        // ---- outputs of this group: its taps of this split's slab (and, G1, the bias sums: every column of accb holds them)
+        if (G == 1 && do_bias && l15 == 0) {
+            const int cf = cfb * 64 + wcs * 16 + 4 * g4;
+            if (cf < p.Cf) *(f32x4*)(p.bslab + (long)z * p.slab_stride + cf) = accb;
+        }
+        const int cs = csb * 64 + wcs * 16 + l15;
+        if (cs < p.S.C) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int ct = 0; ct < CFT; ++ct) {
+                    const int cf = cfb * 64 + ((ct + wcs) & 3) * 16 + 4 * g4;
+                    if (cf >= p.Cf) continue;
+                    float* dst = p.slab + (long)z * p.slab_stride + (((long)(T0 + t) * p.CsOut + p.cs_off + cs) * p.CfOut + cf);
+                    *(f32x4*)dst = acc[t][ct];
+                }
+            }
+        }
+    };
+    if (grp) {
+        run(I1{});
+    } else {
+        run(I0{});
+        bar();  // G0 sits out G1's last M interval
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's last pieces: nothing may land in this workgroup's LDS after it has gone
+}
+
+template <int LSW>
+static hipError_t wgp64_launch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    constexpr int SW = 1 << LSW, TR = 128 >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32, NSW = ((NPIX + 7) / 8 + 7) / 8;
+    if (p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX) return hipErrorInvalidValue;
+    auto kern = igemm_wgp64_kernel<LSW>;
+    const size_t lds = 3 * (size_t)(128 * 128 + NSW * 8 * 1024);
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+// the launches igemm_wgp64 is built for: the 64x64 shape of the 3x3 stride-1 dilation-1 weight gradient, strip widths 16 and 32
+bool igemm_wgp64_supports(int cfg, int ntap, const IgWgradParams& p) {
+    if (cfg != IGW_CFG_64x64 || ntap != 9 || p.stride != 1 || p.dil != 1 || (p.lsw != 4 && p.lsw != 5) || p.sbslab) return false;
+    const int SW = 1 << p.lsw, TR = 128 >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32, NSW = ((NPIX + 7) / 8 + 7) / 8;
+    return p.g.SW == SW && p.g.CW == CW && p.g.npix_max == NPIX && NSW + 2 <= 7 && 3 * (128 * 128 + NSW * 8 * 1024) <= 160 * 1024;
+}
+hipError_t igemm_wgp64_launch(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+    return p.lsw == 4 ? wgp64_launch_one<4>(p, gx, gy, gz, st) : wgp64_launch_one<5>(p, gx, gy, gz, st);
+}
+
 template <int LSW, int DBG = 0, int SCH = 4>
 static hipError_t wgpp_launch_one(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
     constexpr int SW = 1 << LSW, TR = 128 >> LSW;

@@ -733,6 +733,8 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     // RSU_WG_GEN=1: igemm_wgrad everywhere; default: the ping-pong kernel where it is built (same slabs, same bits)
     if (env_int("RSU_WG_GEN", 2) >= 2 && igemm_wgpp_supports(cfg, ntap, p))
         HIP_CHECK_RET(igemm_wgpp_launch(p, pl.gx, pl.gy, pl.nsplit, st));
+    else if (env_int("RSU_WG_GEN", 2) >= 2 && env_int("RSU_WG64", 1) && igemm_wgp64_supports(cfg, ntap, p))
+        HIP_CHECK_RET(igemm_wgp64_launch(p, pl.gx, pl.gy, pl.nsplit, st));
     else
         HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
     if (nslab > 1) {

@@ -173,6 +173,34 @@ def test_pingpong_wgrad_gives_the_bits_of_igemm_wgrad(N, H, W, Cin, Cout, monkey
     assert np.array_equal(out["1"][1].view(np.uint32), out["2"][1].view(np.uint32)), "bias gradient bits differ"
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 41, 64, 64), (1, 150, 140, 64, 64), (3, 21, 37, 72, 56), (1, 12, 140, 200, 64), (2, 34, 34, 128, 40)])
+def test_pingpong_wgrad_64(N, H, W, Cin, Cout, monkeypatch):
+    """igemm_wgp64 (64 gradient channels: the taps dealt over the two wave groups) against igemm_wgrad's 64x64 shape: another
+    summation order of the same products -- equal to fp32 rounding, bias sums included -- and against the oracle"""
+    rng = np.random.RandomState(Cin + Cout + H)
+    Ho, Wo = H - 2, W - 2
+    x, dz = hu.q(_rand(rng, N, H, W, Cin)), hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
+    xd, dzd = hu.dev_bf16(x), hu.dev_bf16(dz)
+    nws = lib().rsu_conv2d_bwd_weight_ws_floats(Cin, Cin, Cout)
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("RSU_WG64", v)
+        dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+        db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+        ws = torch.zeros(nws + 1024, dtype=torch.float32, device=hu.DEV)
+        ws[nws:] = 777.0
+        s = hu.src_of(xd, H, W)
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, hu.stream())
+        assert bool((ws[nws:] == 777.0).all()), "workspace overrun"
+        out[v] = (hu.host(dw), hu.host(db))
+    ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=1)
+    hu.assert_f32_close(out["1"][0], ref_dw, "igemm_wgp64 dW")
+    hu.assert_f32_close(out["1"][1], ref_db, "igemm_wgp64 db")
+    scale = float(np.abs(out["0"][0]).max())
+    assert float(np.abs(out["0"][0] - out["1"][0]).max()) <= 2e-6 * scale + 1e-7
+    assert float(np.abs(out["0"][1] - out["1"][1]).max()) <= 2e-6 * float(np.abs(out["0"][1]).max()) + 1e-7
+
+
 def test_conv2d_bwd_weight_cropped_sources():
     rng = np.random.RandomState(10)
     N, h = 2, 24
