@@ -81,9 +81,9 @@ class Options(object):
             self.rotation_angles = None if not ra else [int(i) for i in ra.split(",")]
 
 
-def pixel_f1(pred_masks, true_masks):
+def pixel_f1(pred_masks, true_masks, threshold=0.5):
     """F1 = 2 / (1/recall + 1/precision) (summary.py:141-147) at pixel level on binarised masks."""
-    p = np.asarray(pred_masks).reshape(-1) > 0.5
+    p = np.asarray(pred_masks).reshape(-1) > threshold
     t = np.asarray(true_masks).reshape(-1) >= 0.5
     tp = float(np.logical_and(p, t).sum())
     if tp == 0:
