@@ -43,11 +43,11 @@ def agg(pat, name):
     return d
 rd, wr = agg("rd", "FETCH_SIZE"), agg("wr", "WRITE_SIZE")
 def conv3(k):
-    return "igemm_pp_kernel" in k or "igemm_wgpp_kernel" in k or ("igemm_fwd2_kernel" in k and ", 9, 3," in k) or ("igemm_wgrad_kernel" in k and ", 9, 3," in k)
+    return "igemm_pp_kernel" in k or "igemm_wgpp_kernel" in k or "igemm_wgp64_kernel" in k or ("igemm_fwd2_kernel" in k and ", 9, 3," in k) or ("igemm_wgrad_kernel" in k and ", 9, 3," in k)
 def wg(k):
-    return "wgrad" in k or "wgpp" in k
+    return "wgrad" in k or "wgpp" in k or "wgp64" in k
 fams = {"igemm_pp + igemm_fwd2 3x3 (forward, backward-data)": lambda k: conv3(k) and not wg(k),
-        "igemm_wgpp + igemm_wgrad 3x3 (weight gradient)": lambda k: conv3(k) and wg(k), "conv3x3 all": conv3}
+        "igemm_wgpp + igemm_wgp64 + igemm_wgrad 3x3 (weight gradient)": lambda k: conv3(k) and wg(k), "conv3x3 all": conv3}
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over python3 bench.py --steps 3 --warmup 1 with the "
                  "tile shapes of the bench run imported (tools/r02_measure.sh); raw counter unit KiB; gfx950: FETCH_SIZE x 2 for 16-byte-per-lane reads",
        "workload": "num_layers=5 root_size=64 patch_size=388 batch 4",
