@@ -340,8 +340,11 @@ class UNet:
         if not self.wstreams or spec in ("0", ""):
             return
         full = _lib.lib().rsu_get_cu_budget()
-        parts = [int(v) for v in spec.split(",")]
-        if len(parts) != len(self.wstreams) + 1:
+        try:
+            parts = [int(v) for v in spec.split(",")]
+        except ValueError:
+            return
+        if len(parts) != len(self.wstreams) + 1 or min(parts) < 1:
             return
         parts = [max(32, v * full // 256 // 8 * 8) for v in parts]  # (a data-parallel run may have lowered the budget)
         self._split = (full, parts[0], parts[1:])
