@@ -174,7 +174,7 @@ def main():
     dp_tune = None
     if bucketer is not None and "RSU_DP_OVERLAP" not in os.environ:
         # untimed: measure both gradient-exchange schedules on this node and keep the faster one (dist.tune_overlap)
-        dp_tune = tune_overlap(bucketer, lambda: run_step(m, bucketer, lr, mu), set_cu_budget=lambda n: call("rsu_set_cu_budget", n))
+        dp_tune = tune_overlap(bucketer, lambda: run_step(m, bucketer, lr, mu), set_cu_budget=lambda n: setattr(m, "backward_cu_budget", n))
     for _ in range(args.warmup):
         run_step(m, bucketer, lr, mu)
     torch.cuda.synchronize()
@@ -281,7 +281,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                    "step_tflops_algorithmic": tot_fl * world * args.steps / dt / 1e12, "loss": loss,
                    "dp_exchange": (None if bucketer is None else
-                                   {"overlapped_buckets": bool(bucketer.overlap), "conv_cu_budget": lib().rsu_get_cu_budget(),
+                                   {"overlapped_buckets": bool(bucketer.overlap), "backward_cu_budget": m.backward_cu_budget or 256,
                                     "min_bucket_MB": bucketer.min_bucket * 4 >> 20,
                                     "tuned_ms_per_step": None if dp_tune is None else {
                                         "%s/%dcu/%dMB" % ("overlapped" if k[0] else "single", k[1], k[2] * 4 >> 20): v

@@ -150,7 +150,7 @@ class ConvolutionalModel:
                     self._bucketer.reset()
                     net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
                     self._bucketer.finish()
-                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=lambda n: call("rsu_set_cu_budget", n))
+                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=lambda n: setattr(self.net, "backward_cu_budget", n))
         # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
         # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
         net.forward_device(keep=float(opts.dropout))

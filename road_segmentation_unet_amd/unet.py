@@ -109,6 +109,8 @@ class UNet:
         self.wstream = None    # side stream for the weight-gradient launches (see _Side); wstreams: all of them
         self.wstreams = []
         self._split = None     # (full, main, [side ...]) CU budgets while a backward pass shares the chip between the streams
+        self.backward_cu_budget = None   # CUs the backward launches may plan for in total (None: the library's budget)
+        self._budget_before = 256
         self._side_rr = 0
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
@@ -335,25 +337,32 @@ class UNet:
     # WORKGROUP (a 295-KB slab each, written and read back by the reduce kernel): half the workgroups, half that traffic --
     # and persistent kernels on fewer CUs lose less to their last, partly filled round of tiles. "0" = both plan for every CU.
     def _begin_split(self):
+        """CU budgets of the backward pass: `backward_cu_budget` (set by the data-parallel host: CUs left to RCCL's channel workgroups
+        while the gradient exchange overlaps the backward pass; the forward pass keeps the whole chip) shared out between the streams"""
         self._split = None
+        self._budget_before = _lib.lib().rsu_get_cu_budget()
+        full = self.backward_cu_budget or self._budget_before
         spec = os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT)
-        if not self.wstreams or spec in ("0", ""):
+        parts = None
+        if self.wstreams and spec not in ("0", ""):
+            try:
+                parts = [int(v) for v in spec.split(",")]
+            except ValueError:
+                parts = None
+            if parts is not None and (len(parts) != len(self.wstreams) + 1 or min(parts) < 1):
+                parts = None
+        if parts is None:
+            if full != self._budget_before:
+                call("rsu_set_cu_budget", full)
             return
-        full = _lib.lib().rsu_get_cu_budget()
-        try:
-            parts = [int(v) for v in spec.split(",")]
-        except ValueError:
-            return
-        if len(parts) != len(self.wstreams) + 1 or min(parts) < 1:
-            return
-        parts = [max(32, v * full // 256 // 8 * 8) for v in parts]  # (a data-parallel run may have lowered the budget)
+        parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
         self._split = (full, parts[0], parts[1:])
         call("rsu_set_cu_budget", parts[0])
 
     def _end_split(self):
-        if self._split is not None:
-            call("rsu_set_cu_budget", self._split[0])
-            self._split = None
+        self._split = None
+        if _lib.lib().rsu_get_cu_budget() != self._budget_before:
+            call("rsu_set_cu_budget", self._budget_before)
 
     class _Side:
         """`with UNet._Side(net) as side:` -- launches inside go to the next side stream (round robin); side.ws is its workspace"""
