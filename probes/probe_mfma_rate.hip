@@ -215,6 +215,19 @@ int main() {
     std::vector<unsigned short> h(4096 * 8);
     for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff)) ^ ((rand() & 1) << 15);  // bf16 values of magnitude ~1, random sign
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    if (getenv("PROBE_SHAPES")) {   // 16x16x32 against 32x32x16 beside a partner that reads / computes addresses (same FLOPs per M round)
+        for (int blocks : {256}) {
+            run<2, 16, 0, 0, false, false>("ping-pong, 16 x 16x16x32 per M round", 512, blocks, src, out, cyc);
+            run<2, 16, 0, 0, true, false>("ping-pong, 8 x 32x32x16 per M round", 512, blocks, src, out, cyc);
+            run<3, 16, 8, 0, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read_b128", 512, blocks, src, out, cyc);
+            run<3, 16, 8, 0, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read_b128", 512, blocks, src, out, cyc);
+            run<5, 16, 8, 12, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 12 VALU + 24 SALU", 512, blocks, src, out, cyc);
+            run<5, 16, 8, 12, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 12 VALU + 24 SALU", 512, blocks, src, out, cyc);
+            run<5, 16, 8, 4, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 4 VALU + 8 SALU", 512, blocks, src, out, cyc);
+            run<5, 16, 8, 4, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 4 VALU + 8 SALU", 512, blocks, src, out, cyc);
+        }
+        return 0;
+    }
     for (int blocks : {1, 256}) {
         run<0, 16, 0, 0, false, false>("free-running, 1 wave/SIMD, 16 x 16x16x32", 256, blocks, src, out, cyc);
         run<0, 16, 0, 0, false, true>("free-running, 1 wave/SIMD, 16 x 16x16x32, AGPR acc", 256, blocks, src, out, cyc);
