@@ -56,6 +56,10 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
 bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
+// fourth generation (igemm_pp32.hip): igemm_pp with 32x32x16 MFMAs; results equal to fp32 rounding, not bit for bit
+hipError_t igemm_pp32_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
+bool igemm_pp32_has(int cfg);
+bool igemm_pp32_supports(int cfg, const IgFwdParams& p);
 
 // ---------------------------------------------------------------------------------------------
 // igemm_ct (igemm_ct.hip): the 2x2 stride-2 transposed convolution as a ping-pong GEMM over the low-resolution pixels m = (n, y, x)

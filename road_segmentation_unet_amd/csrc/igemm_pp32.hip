@@ -1,0 +1,736 @@
+// igemm_pp32: igemm_pp.hip (ping-pong wave groups, same streams, rings, tile shapes, packed weights and LDS images) with the matrix
+// work issued as v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_16x16x32_bf16: half as many MFMA instructions for the same operand
+// bytes, each holding the SIMD's vector issue port for 8 of its 32 cycles instead of 8 of 16 -- which is what the partner wave's LDS
+// reads, LDS-DMA issues and bookkeeping compete with (probes/probe_mfma_rate.hip, profiles/r02/mfma_shape_probe.txt: a round with a
+// kernel-like R interval beside it takes 697 cycles instead of 896).
+//
+// What changes against igemm_pp (everything else, including every comment on the streams, is as there):
+//   * a wave's 64 x 64 tile is 2 x 2 accumulators of 32 x 32 (16 registers each); per tap and 32-channel chunk it issues 2 k-halves x
+//     2 x 2 MFMAs; the same 24 fragment reads per 3-tap stage.
+//   * fragments come from the SAME LDS images: the A operand of a 32 x 32 x 16 MFMA wants, in lane l, row l & 31 and the 8 k values
+//     8 * (l >> 5) ..: that is 16-row tile (l & 31) >> 4 of the pair, lane position (2 * ks + (l >> 5)) * 16 + (l & 15) of its 1-KiB
+//     block (ks = k-half); the B operand pixel l & 31 of the 32-pixel fragment, 16-byte chunk 2 * ks + (l >> 5) of its 64 bytes.
+//   * a lane's 16 results of a tile are rows 8 j + 4 (l >> 5) + i (j, i = 0..3) of pixel l & 31; with the row permutation the weight
+//     pack already has (channel 8 g + 4 t + i in tile t, row 4 g + i) those are channels 8 h .. 8 h + 7 (j = 0, 2) and 16 + 8 h ..
+//     (j = 1, 3) of the 32-channel group, h = l >> 5: two 16-byte stores per tile, as many stores per wave as before.
+//   * summation order: per output the taps in order, inside a tap k-half 0 then 1 -- not the order inside a 16x16x32 MFMA: results
+//     agree with igemm_fwd2 / igemm_pp to fp32 rounding, not bit for bit. Every tile shape of THIS kernel gives the same bits.
+//   * only the shapes with an even number of pixel fragments per wave (128x256, 64x512, 128x128, 64x256).
+#include <type_traits>
+
+#include "igemm.h"
+
+#define RSU_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define RSU_SENT 0x80000000u   // voffset that the range check always rejects (num_records = 0x7fffffff)
+
+namespace {
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned x) {
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    s2 h = __builtin_bit_cast(s2, x);
+    h = __builtin_elementwise_max(h, s2{0, 0});
+    return __builtin_bit_cast(unsigned, h);
+}
+}  // namespace
+
+// STAMP: diagnostic build (RSU_FWD_DBG bit 7 + RSU_STAMP_PTR): every wave notes s_memtime in front of and behind each barrier
+// (in LDS, dumped to p.stamps at the end: [block][wave][PP_NSTAMP]); tools/pp_stamps.py prints the interval lengths. Never on the
+// product path.
+#define PP_NSTAMP 640
+// The halo DMA pieces of a chunk are dealt over five (group, stage) slots G0/0, G1/0, G0/1, G1/1, G0/2 (NAW: pieces per wave in
+// each slot; their sum * 4 * 16 = halo pixels at most); wave w4 of the slot's group issues piece (first(slot) + t) * 4 + w4.
+// WP0 = weight pieces of a stage issued by each G0 wave (the G1 waves issue the rest)
+namespace {
+// (NAW packs the five per-slot counts, 4 bits each, slot 0 in the lowest nibble)
+constexpr int pp_na_slot(int NAW, int k) { return (NAW >> (4 * k)) & 15; }
+constexpr int pp_na(int NAW, int g, int j) { return g == 0 ? pp_na_slot(NAW, 2 * j) : (j < 2 ? pp_na_slot(NAW, 2 * j + 1) : 0); }
+constexpr int pp_na_first(int NAW, int g, int j) {  // per-wave piece index of the slot's first piece
+    int n = 0;
+    for (int k = 0; k < (g == 0 ? 2 * j : 2 * j + 1); ++k) n += pp_na_slot(NAW, k);
+    return n;
+}
+constexpr int pp_na_total(int NAW, int g) { return pp_na(NAW, g, 0) + pp_na(NAW, g, 1) + pp_na(NAW, g, 2); }
+constexpr int pp_na_idx(int NAW, int g, int j) {  // index of the slot's first piece in the wave's own offset array
+    int n = 0;
+    for (int k = 0; k < j; ++k) n += pp_na(NAW, g, k);
+    return n;
+}
+}  // namespace
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+igemm_pp32_kernel(const IgFwdParams p) {
+    constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
+    static_assert(WCO * WPX == NW, "eight waves: two per SIMD");
+    constexpr int TN = WCO * CT * 16, TM = WPX * PT * 16;
+    constexpr int WT = TN / 16;
+    constexpr int WBUF = TPS * WT * 1024;
+    constexpr int NWB = 3, NAB = 2;
+    // weight pieces of a stage (3 * WT): waves of G0 issue WP0 each (pieces q*4 + w4), waves of G1 WP1 each (pieces (WP0 + q)*4 + w4)
+    constexpr int WP1 = TPS * WT / 4 - WP0;
+    constexpr int WPM = WP1 > WP0 ? WP1 : (WP0 > 0 ? WP0 : 1);
+    constexpr int NAV = pp_na_total(NAW, 0) > pp_na_total(NAW, 1) ? pp_na_total(NAW, 0) : pp_na_total(NAW, 1);
+    static_assert((WP0 + WP1) * 4 == TPS * WT && WP0 >= 0 && WP1 >= 1, "weight pieces per stage");
+    constexpr int NST = (CT / 2) * PT;   // epilogue buffer stores per wave per tile (always issued): 2 per 32 x 32 accumulator
+    static_assert((CT % 2) == 0 && (PT % 2) == 0, "32 x 32 accumulator tiles");
+    constexpr int CT2 = CT / 2, PT2 = PT / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+    // geometry is a compile-time constant of the instantiation (strip width 2^LSW, 3x3 taps, dilation 1, stride 1): halo addresses
+    // become immediate offsets of the LDS reads and most of the scalar arithmetic of an R interval disappears (an R-interval
+    // instruction costs ~6 cycles of a budget of ~290: probes/probe_mfma_rate.hip)
+    constexpr int SW = 1 << LSW, lsw = LSW, TR = TM >> LSW;
+    constexpr int CW = (SW + 2 + 7) / 8 * 8;              // halo row pitch in pixels (plan_geo_aligned)
+    constexpr int NPIX = ((TR + 2) * CW + 31) / 32 * 32;  // halo pixels per slot
+    constexpr int ABUF = NPIX * 64;
+    constexpr int ROWB = CW * 64;                         // one kernel row down in the halo tile
+    constexpr int a_base = 0;                             // LDS: [halo slot 0][halo slot 1][weight slots 0..2][scratch][bias]
+    constexpr int WBASE = NAB * ABUF;
+    constexpr int dummy_base = WBASE + NWB * WBUF;        // 1 KiB scratch slot for padding loads
+    static_assert(ABUF + 2 * ROWB < 65536, "halo offsets must fit the 16-bit offset field of ds_read");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wco = wave / WPX, wpx = wave % WPX;
+    const int l15 = lane & 15, l31 = lane & 31, h32 = lane >> 5;
+
+    // ---- this workgroup's tile list (XCD-aware numbering as in igemm_fwd2)
+    int vid = blockIdx.x;
+    {
+        const int q = gridDim.x >> 3, r = gridDim.x & 7, x = vid & 7;
+        vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
+    }
+    const int cob = vid % p.ncob;
+    const int tile0 = vid / p.ncob, tstride = gridDim.x / p.ncob;
+    const int tpi = p.g.nstrips * p.g.tiles_per_strip;
+    const int ntile_m = p.N * tpi;
+    const int my_tiles = tile0 < ntile_m ? (ntile_m - tile0 + tstride - 1) / tstride : 0;
+    if (my_tiles == 0) return;
+    const int nchunks = p.nchunk[0] + p.nchunk[1] + p.nchunk[2];
+    const int GC = my_tiles * nchunks;  // chunks in this workgroup's stream
+
+    // this workgroup's tiles are tile0, tile0 + tstride, ...: (image, strip, row in strip) of the first one by division, then stepped --
+    // a run-time division costs ~20 vector instructions, and a vector instruction of an R interval waits for a gap between the
+    // partner wave's MFMAs (~17 cycles each, tools/pp_stamps.py)
+    struct Tile { int n, x0, y0; };
+    struct Pos { int n, strip, row; };
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto split = [&](int t) {
+        const int n = t / tpi, r = t - n * tpi;
+        const int strip = r / p.g.tiles_per_strip;
+        return Pos{sgpr(n), sgpr(strip), sgpr(r - strip * p.g.tiles_per_strip)};
+    };
+    const Pos tstep = split(tstride);
+    auto advance = [&](Pos& q) {
+        q.row += tstep.row;
+        if (q.row >= p.g.tiles_per_strip) { q.row -= p.g.tiles_per_strip; ++q.strip; }
+        q.strip += tstep.strip;
+        if (q.strip >= p.g.nstrips) { q.strip -= p.g.nstrips; ++q.n; }
+        q.n += tstep.n;
+    };
+    auto tile_at = [&](const Pos& q) { return Tile{q.n, q.strip * SW, q.row * TR}; };
+
+    // ---- workgroup constants (per lane)
+    int boff[2][PT2][KW];   // [k-half][32-pixel fragment][kx]: byte offset (inside a halo slot) of this lane's 16-byte piece
+#pragma unroll
+    for (int pt = 0; pt < PT2; ++pt) {
+        const int ml = (wpx * PT2 + pt) * 32 + l31;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        const int hp0 = ty * CW + tx;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int hp = hp0 + kx;
+            // chunk swizzle by the pixel's COLUMN in the halo tile, (cc >> 2) & 3 (igemm_pp's (hp >> 1) & 2 serves 16-pixel fragments; with
+            // 32 pixels per fragment it costs every read a 2-way bank conflict -- tools/lds_bank_sim.py rules, SQ_LDS_BANK_CONFLICT 0.33 per
+            // active cycle measured; this one is conflict free for strip widths >= 16). A ky shift keeps the column, hence the swizzle.
+            const int swz = ((tx + kx) >> 2) & 3;
+            boff[0][pt][kx] = (hp << 6) + ((h32 ^ swz) << 4);
+            boff[1][pt][kx] = boff[0][pt][kx] ^ 32;                          // chunk 2 + h32 of the pixel's 64 bytes
+        }
+    }
+    // this lane's 16 bytes inside the wave's first PAIR of weight tiles (slot 0, k-half 0): tile l31 >> 4 of the pair, lane position
+    // h32 * 16 + l15 of its block; k-half 1 is 512 bytes further
+    const int afrag = WBASE + ((wco * CT + (l31 >> 4)) * 64 + h32 * 16 + l15) * 16;
+    constexpr int npieces = NPIX >> 4;
+    const int lq = lane >> 2;
+    auto mk = [&](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0x7fffffff, 0x00020000); };
+
+    // ---- weight prefetch stream (G1). Stage s of a tile is the contiguous block [s*3 .. s*3+3) x [all 16-row tiles] of the packed
+    // weights; a wave's WPS pieces have constant offsets inside it (folded into the per-lane voffset), the stage is one scalar
+    // offset that advances by a constant and rewinds per tile. The stream never ends: behind the last stage it simply starts the
+    // tile's weights again (valid memory, slots nobody reads), so the counted waits hold to the very end.
+    const int nstage_tile = nchunks * 3;
+    const unsigned stage_bytes = (unsigned)TPS * p.ntiles_w * 1024;
+    const unsigned w_tile_soff = (unsigned)(p.tile_off + cob * WT) * 1024u;
+    unsigned w_soff = w_tile_soff;     // stage to prefetch next
+    int w_sit = 0;                     // its stage index inside the tile
+    unsigned w_voff[WPM];              // per-lane byte offset of this wave's piece q inside a stage block
+#pragma unroll
+    for (int q = 0; q < WPM; ++q) {
+        const int i = ((grp ? WP0 : 0) + q) * NG + w4;
+        const int tap_l = i / WT, tl = i - tap_l * WT;
+        const bool real = (q < (grp ? WP1 : WP0)) && (p.tile_off + cob * WT + tl < p.ntiles_w);
+        w_voff[q] = real ? (unsigned)((tap_l * p.ntiles_w + tl) * 1024 + lane * 16) : RSU_SENT;
+    }
+    auto issue_w = [&](auto gc_, int slot) {
+        constexpr int G = decltype(gc_)::value;
+        const __amdgpu_buffer_rsrc_t rw = mk(p.wp);
+#pragma unroll
+        for (int q = 0; q < (G ? WP1 : WP0); ++q) bdma16(rw, w_voff[q], w_soff, (void*)(lds + WBASE + slot * WBUF + (((G ? WP0 : 0) + q) * NG + w4) * 1024));
+        if (++w_sit == nstage_tile) {
+            w_sit = 0;
+            w_soff = w_tile_soff;
+        } else {
+            w_soff += stage_bytes;
+        }
+    };
+    // ---- halo prefetch stream: NAW * 4 pieces per chunk; clipped / padded pixels come back as zeros. Every wave keeps the stream
+    // state (scalars) and the per-lane offsets of ITS pieces.
+    unsigned a_voff[NAV > 0 ? NAV : 1];  // per-lane byte offset of this wave's piece inside the current source, or RSU_SENT
+    const char* a_ptr = nullptr;   // current source, shifted back by the padding so that every in-window offset is >= 0
+    unsigned a_soff = 0;           // byte offset of the (padded) halo origin + channel chunk in that source
+    int a_crem = 0;                // channels left in the current source (>= 32 except in a partial last chunk)
+    int a_cl = 0;                  // chunk (inside its tile) of the next halo to prefetch
+    int a_next_src = 0;            // chunk index at which the next source begins
+    int a_si = 0;                  // current source
+    int ia_slot = 0;               // ring slot of the next halo
+    auto my_piece = [&](int idx) {  // halo piece (per chunk) behind entry idx of this wave's offset array
+        int pw = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i0 = grp ? pp_na_idx(NAW, 1, j) : pp_na_idx(NAW, 0, j);
+            const int n = grp ? pp_na(NAW, 1, j) : pp_na(NAW, 0, j);
+            const int f = grp ? pp_na_first(NAW, 1, j) : pp_na_first(NAW, 0, j);
+            if (idx >= i0 && idx < i0 + n) pw = f + idx - i0;
+        }
+        return pw * NG + w4;
+    };
+    auto setup_a = [&](const Tile& T, int si) {
+        const bf16_t* sptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
+        const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
+        const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
+        const int sC = si == 0 ? p.src[0].C : (si == 1 ? p.src[1].C : p.src[2].C);
+        const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
+        const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
+        a_ptr = (const char*)(sptr - ((long)p.pad * sW + p.pad) * sC);
+        a_soff = (unsigned)((((long)(T.n * sH + T.y0 + soy) * sW + (T.x0 + sox)) * sC) * 2);
+        a_crem = sC;
+        const int iy0 = T.y0 - p.pad, ix0 = T.x0 - p.pad;
+#pragma unroll
+        for (int q = 0; q < NAV; ++q) {
+            const int hp = my_piece(q) * 16 + lq;
+            const int rr = hp / CW;   // compile-time divisor
+            const int cc = hp - rr * CW;
+            const int kg8 = ((lane & 3) ^ ((cc >> 2) & 3)) * 8;
+            const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win) &&
+                            (q < (grp ? pp_na_total(NAW, 1) : pp_na_total(NAW, 0)));
+            a_voff[q] = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
+        }
+    };
+    Pos ppos = split(tile0);
+    Tile ptile = tile_at(ppos);     // tile whose halo is being prefetched
+    int pk = 0;                 // index of ptile in this workgroup's list
+    bool a_started = false;
+    auto a_begin = [&]() {  // the next chunk of the stream: moves on to the next source / tile where one ends
+        if (a_cl == 0) {
+            if (a_started) {
+                if (pk + 1 < my_tiles) {  // behind the last tile the stream prefetches that tile again (valid memory, a slot nobody reads)
+                    ++pk;
+                    advance(ppos);
+                }
+                if (!(DBG && (p.dbg & 256))) {   // (dbg bit 8: timing without the prefetch stream's tile change)
+                    ptile = tile_at(ppos);
+                    setup_a(ptile, 0);
+                }
+                a_si = 0;
+                a_next_src = p.nchunk[0];
+            }
+        } else if (a_cl == a_next_src) {
+            ++a_si;
+            a_next_src += a_si == 1 ? p.nchunk[1] : p.nchunk[2];
+            setup_a(ptile, a_si);
+        }
+        a_started = true;
+    };
+    auto a_pieces = [&](auto gc_, auto jc_) {  // this wave's pieces of slot (G, J)
+        constexpr int G = decltype(gc_)::value, J = decltype(jc_)::value;
+        constexpr int I0 = pp_na_idx(NAW, G, J), N = pp_na(NAW, G, J), F = pp_na_first(NAW, G, J);
+        if constexpr (N > 0) {
+            const __amdgpu_buffer_rsrc_t rs = mk(a_ptr);
+            const int dst = a_base + ia_slot * ABUF;
+            if (a_crem >= 32) {
+#pragma unroll
+                for (int t = 0; t < N; ++t) {
+                    const int j = (F + t) * NG + w4;
+                    bdma16(rs, a_voff[I0 + t], a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+                }
+            } else {  // partial last chunk of a source whose channel count is not a multiple of 32: the missing channels read as zeros
+#pragma unroll
+                for (int t = 0; t < N; ++t) {
+                    const int j = (F + t) * NG + w4;
+                    const int hp = j * 16 + lq;
+                    const int kg8 = ((lane & 3) ^ (((hp % CW) >> 2) & 3)) * 8;
+                    bdma16(rs, kg8 < a_crem ? a_voff[I0 + t] : RSU_SENT, a_soff, (void*)(lds + (j < npieces ? dst + j * 1024 : dummy_base)));
+                }
+            }
+        }
+    };
+    auto a_end = [&]() {
+        ia_slot ^= 1;
+        a_soff += 64;
+        a_crem -= 32;
+        a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
+    };
+
+    // bias of this workgroup's TN channels lives in LDS (behind the scratch slot)
+    const int bias_base = dummy_base + 1024;
+    const int stamp_base = bias_base + 512;
+    int stamp_i = 0;
+    // STAMP builds also sum the cycles of named segments of the R intervals (reported in the last stamps of the wave)
+    unsigned long long seg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seg_t0 = 0;
+    auto seg_begin = [&]() {
+        if constexpr (STAMP) seg_t0 = __builtin_amdgcn_s_memtime();
+    };
+    auto seg_end = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            seg_sum[k] += t - seg_t0;
+            seg_t0 = t;
+        }
+    };
+    auto stamp = [&]() {
+        if constexpr (STAMP) {
+            if (stamp_i < PP_NSTAMP - 10) {
+                const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+                if (lane == 0) *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + stamp_i) * 4) = t;
+            }
+            ++stamp_i;
+        }
+    };
+    if (threadIdx.x < TN) {
+        const int co = cob * TN + threadIdx.x;
+        const float bvv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        *(__attribute__((address_space(3))) float*)(lds + bias_base + threadIdx.x * 4) = bvv;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ordinary loads before the LDS-DMA stream starts
+
+    // scalar byte offset of a tile's first output pixel (+ this wave's first channel) and per-lane offset of epilogue store e
+    auto out_sbase = [&](const Tile& T) {
+        return (unsigned)((((long)(T.n * p.oH + T.y0) * p.oW + T.x0) * p.outC + cob * TN + wco * (CT / 2) * 32) * 2);
+    };
+    // epilogue store e = (pt2 * CT2 + ct2) * 2 + half: pixel l31 of 32-pixel fragment pt2, channels 16 * half + 8 * h32 .. + 7 of the
+    // wave's 32-channel group ct2
+    auto out_voff = [&](const Tile& T, int e) {
+        const int half = e & 1, ct2 = (e >> 1) % CT2, pt = (e >> 1) / CT2;
+        const int ml = (wpx * PT2 + pt) * 32 + l31;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
+        const int ovoff_pt = ((ty * p.oW + tx) * p.outC + 8 * h32) * 2;
+        const int co = cob * TN + (wco * CT2 + ct2) * 32 + half * 16 + 8 * h32;
+        return (pok && co < p.Cout) ? (unsigned)(ovoff_pt + ct2 * 64 + half * 32) : RSU_SENT;
+    };
+// store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard). The leading s_nop 4:
+// under register pressure the compiler parks descriptor words in VGPR lanes and brings them back through v_readlane right in front
+// of the store -- a VALU write of an SGPR that a VMEM instruction reads needs five wait states, which hipcc does not add for asm
+#define PP_STORE(R, VOFF) \
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory")
+#define PP_STORE64(R, VOFF) \
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:64\n\ts_nop 3" ::"v"(R), "v"(VOFF), "s"(orsrc), "s"(sbase) : "memory")
+    // tiles that lie inside the output (all but the last row / strip of an image) store through per-lane offsets computed once
+    unsigned ovoff[PT2];
+#pragma unroll
+    for (int pt = 0; pt < PT2; ++pt) {
+        const int ml = (wpx * PT2 + pt) * 32 + l31;
+        const int ty = ml >> lsw, tx = ml & (SW - 1);
+        ovoff[pt] = (unsigned)(((ty * p.oW + tx) * p.outC + 8 * h32) * 2);
+    }
+    const bool co_inside = cob * TN + TN <= p.Cout;
+    // the eight floats behind store e of a tile: rows 8 j + 4 h32 + i for j = half, half + 2 (registers 4 j + i)
+    auto epi_vals = [&](const f32x16& t, int half, float (&v)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = t[4 * half + i];
+            v[4 + i] = t[8 + 4 * half + i];
+        }
+    };
+    auto epilogue = [&](const Tile& T, f32x16(&acc)[CT2][PT2]) {
+        const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
+        const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
+        const unsigned sbase = out_sbase(T);
+        const bool inside = co_inside && (T.y0 + TR <= p.Ho) && (T.x0 + SW <= p.Wo);  // wave-uniform
+        unsigned voffs[NST];
+        if (inside) {   // (wave-uniform)
+#pragma unroll
+            for (int e = 0; e < NST; ++e) voffs[e] = ovoff[(e >> 1) / CT2] + ((e >> 1) % CT2) * 64 + (e & 1) * 32;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NST; ++e) voffs[e] = out_voff(T, e);
+        }
+        seg_end(6);
+        if (!p.accumulate) {
+            // forward and backward-data without an AddN (see igemm_pp.hip): packed bf16 result, ReLU as a packed int16 max, the ReLU
+            // mask of backward-data as a packed 0 / 0xffff word; one straight-line copy with and one without the mask
+            typedef __attribute__((ext_vector_type(2))) short s2;
+            const short fl = p.relu ? (short)0 : (short)-32768;
+            const s2 floor2 = {fl, fl};
+            auto body = [&](const bool MASK) __attribute__((always_inline)) {
+                u32x4 mk4[NST];
+                if (MASK) {
+#pragma unroll
+                    for (int e = 0; e < NST; ++e)
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(mk4[e]) : "v"(voffs[e]), "s"(mrsrc), "s"(sbase) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int e = 0; e < NST; ++e) asm volatile("" : "+v"(mk4[e]));
+                }
+#pragma unroll
+                for (int e = 0; e < NST; ++e) {
+                    const int half = e & 1, ct2 = (e >> 1) % CT2, pt = (e >> 1) / CT2;
+                    float v[8];
+                    epi_vals(acc[ct2][pt], half, v);
+                    u32x4 r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, pack_bf2(v[2 * i], v[2 * i + 1])), floor2));
+                    if (MASK) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i]);
+                    }
+                    if (DBG && (p.dbg & 512)) {
+                        asm volatile("" ::"v"(r));
+                    } else {
+                        PP_STORE(r, voffs[e]);
+                    }
+                }
+            };
+            if (p.mask_src) body(true); else body(false);
+            return;
+        }
+        // AddN (+ mask): float arithmetic per element, all loads of the tile requested before the first is used
+        u32x4 mk4[NST], ob4[NST];
+#pragma unroll
+        for (int e = 0; e < NST; ++e) {
+            if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
+            ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < NST; ++e) {
+            const int half = e & 1, ct2 = (e >> 1) % CT2, pt = (e >> 1) / CT2;
+            float v[8];
+            epi_vals(acc[ct2][pt], half, v);
+            if (p.mask_src) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!(bf_lo(mk4[e][i]) > 0.f)) v[2 * i] = 0.f;
+                    if (!(bf_hi(mk4[e][i]) > 0.f)) v[2 * i + 1] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] += bf_lo(ob4[e][i]);
+                v[2 * i + 1] += bf_hi(ob4[e][i]);
+            }
+            unsigned r0 = pack_bf2(v[0], v[1]), r1 = pack_bf2(v[2], v[3]), r2 = pack_bf2(v[4], v[5]), r3 = pack_bf2(v[6], v[7]);
+            if (p.relu) {
+                r0 = relu_pk_bf16(r0);
+                r1 = relu_pk_bf16(r1);
+                r2 = relu_pk_bf16(r2);
+                r3 = relu_pk_bf16(r3);
+            }
+            const u32x4 r = {r0, r1, r2, r3};
+            PP_STORE(r, voffs[e]);
+        }
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: every wave issues its share of the halo of chunk 0 and of the weights of stages 0 and 1 and waits for all of
+    // it; one barrier publishes the lot (raw barrier: __syncthreads() would drain the LDS-DMA stream on every later use; the bias
+    // words above are the only ordinary LDS stores)
+    setup_a(ptile, 0);
+    a_next_src = p.nchunk[0];
+    a_begin();
+    if (!(DBG && (p.dbg & 2))) {
+        if (grp) {
+            a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            a_pieces(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        } else {
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            a_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        }
+    }
+    a_end();
+    if (!(DBG && (p.dbg & 1))) {
+        if (grp) {
+            issue_w(std::integral_constant<int, 1>{}, 0);
+            issue_w(std::integral_constant<int, 1>{}, 1);
+        } else {
+            issue_w(std::integral_constant<int, 0>{}, 0);
+            issue_w(std::integral_constant<int, 0>{}, 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    bar();
+    if (grp) bar();  // G1 sits out interval 0
+
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (STAMP) {
+        clk0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    // ---- the chunk stream, one copy of the loop per wave group (no group tests inside), two chunks per iteration (the halo slot of a
+    // chunk is its parity: every LDS address of an R interval is a per-lane constant plus an immediate). Accumulators live across
+    // the loop; a tile starts them at the bias and ends with its epilogue, which opens the wave's next R interval.
+    f32x16 acc[CT2][PT2];
+    // every accumulator starts at the bias of its rows (register 4 j + i of a lane = row 8 j + 4 h32 + i = channel 8 h32 + i (j = 0),
+    // 16 + 8 h32 + i (j = 1), 8 h32 + 4 + i (j = 2), 16 + 8 h32 + 4 + i (j = 3) of the 32-channel group). Done for the first tile in
+    // front of the loop and for every other tile right behind the previous tile's epilogue, in the interval both groups spend on
+    // their epilogues with no MFMAs beside them (vector moves are cheap there; beside an MFMA stream each costs ~17 cycles)
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int c2 = 0; c2 < CT2; ++c2) {
+            const __attribute__((address_space(3))) float* bp = (const __attribute__((address_space(3))) float*)(lds + bias_base) + (wco * CT2 + c2) * 32 + 8 * h32;
+            const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(bp), b1 = *(const __attribute__((address_space(3))) f32x4*)(bp + 16),
+                        b2 = *(const __attribute__((address_space(3))) f32x4*)(bp + 4), b3 = *(const __attribute__((address_space(3))) f32x4*)(bp + 20);
+            f32x16 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t[i] = b0[i];
+                t[4 + i] = b1[i];
+                t[8 + i] = b2[i];
+                t[12 + i] = b3[i];
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < PT2; ++p2) {
+                acc[c2][p2] = t;
+                asm volatile("" : "+v"(acc[c2][p2]));
+            }
+        }
+    };
+    auto run_stream = [&](auto gconst) {
+        constexpr int G = decltype(gconst)::value;
+        int c = 0;               // chunk inside the current tile
+        int ck = 0;              // current tile
+        Pos cpos = split(tile0);
+        Tile ctile = tile_at(cpos);
+        init_acc();
+        auto chunk = [&](auto parc, int gc) {
+            constexpr int PAR = decltype(parc)::value;
+            seg_begin();
+            seg_end(2);
+            const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
+            auto phase = [&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                // ================= R interval: the stage's fragment reads + bookkeeping for the stages ahead
+                bf16x8 fa[TPS][CT2][2], fb[TPS][PT2][2];   // [tap][32-row / 32-pixel fragment][k-half]
+                seg_begin();
+                if (!(DBG && (p.dbg & 32))) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
+#pragma unroll
+                    for (int tl = 0; tl < TPS; ++tl) {
+#pragma unroll
+                        for (int c2 = 0; c2 < CT2; ++c2)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                fa[tl][c2][ks] = *(const __attribute__((address_space(3))) bf16x8*)(lds + afrag + J * WBUF + (tl * WT + 2 * c2) * 1024 + ks * 512);
+#pragma unroll
+                        for (int p2 = 0; p2 < PT2; ++p2)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                fb[tl][p2][ks] = *(const __attribute__((address_space(3))) bf16x8*)(lds + boff[ks][p2][tl] + (a_base + PAR * ABUF + J * ROWB));
+                    }
+                }
+                seg_end(3);
+                // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
+                if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
+                    if (!(DBG && (p.dbg & 2))) {
+                        if constexpr (J == 0) a_begin();
+                        a_pieces(gconst, jc);
+                    }
+                }
+                if constexpr (J == 2) a_end();
+                if constexpr ((G ? WP1 : WP0) > 0) {
+                    if (!(DBG && (p.dbg & 1))) issue_w(gconst, (J + 2) % NWB);
+                }
+                seg_end(4);
+                if constexpr (G == 1) {
+                    // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
+                    if (J == 0 && after_epi) {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
+                    } else {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
+                seg_end(5);
+                stamp();
+                bar();
+                stamp();
+                // ================= M interval: the MFMAs of this stage, nothing else
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if (!(DBG && (p.dbg & 32)))
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)   // (k-half outside the tiles: an accumulator is revisited 4 MFMAs = 128 cycles later)
+#pragma unroll
+                        for (int p2 = 0; p2 < PT2; ++p2)
+#pragma unroll
+                            for (int c2 = 0; c2 < CT2; ++c2) mfma32_bf16_inplace(acc[c2][p2], fa[tl][c2][ks], fb[tl][p2][ks]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
+                    if (J == 0 && after_epi) {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
+                    } else if (J == 2) {
+                        RSU_WAIT_VMCNT(WP0);
+                    } else {
+                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0);
+                    }
+                }
+                if (J == 2 && c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
+                stamp();
+                bar();
+                stamp();
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            if (c == nchunks - 1) {
+                // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
+                // Tile boundary: both groups store the finished tile in ONE interval of their own, with no MFMAs beside it. A vector
+                // instruction next to the partner's MFMA stream waits ~17 cycles for an issue gap (tools/pp_stamps.py): folded into the
+                // next R interval, each group's epilogue made that interval ~2500 cycles longer than the partner's MFMAs, twice per
+                // tile. Now G0 sits out G1's last MFMA interval, both run their epilogues together at the full issue rate, and G1 sits
+                // out G0's first R interval of the next tile: two short extra intervals instead of two long ones.
+                if constexpr (G == 0) bar();
+                seg_begin();
+                if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
+                seg_end(0);
+                if (!(DBG && (p.dbg & 16))) init_acc();   // the next tile's accumulators (dbg bit 4: timing without)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bar();
+                if constexpr (G == 1) bar();
+                c = 0;
+                ++ck;
+                if (ck < my_tiles && !(DBG && (p.dbg & 64))) {   // (dbg bit 6: timing without the tile change)
+                    advance(cpos);
+                    ctile = tile_at(cpos);
+                }
+                seg_end(1);
+            } else {
+                ++c;
+            }
+        };
+        for (int gc = 0; gc < GC; gc += 2) {
+            chunk(std::integral_constant<int, 0>{}, gc);
+            if (gc + 1 >= GC) break;
+            chunk(std::integral_constant<int, 1>{}, gc + 1);
+        }
+    };
+    if (grp) run_stream(std::integral_constant<int, 1>{}); else run_stream(std::integral_constant<int, 0>{});
+    if (!grp) bar();  // G0 sits out the last interval (G1's last epilogue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in this workgroup's LDS after it has gone
+    if constexpr (STAMP) {
+        if (p.stamps) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned dclk = (unsigned)(__builtin_amdgcn_s_memtime() - clk0), drt = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+            for (int i = lane; i < PP_NSTAMP; i += 64)
+                p.stamps[((long)blockIdx.x * NW + wave) * PP_NSTAMP + i] =
+                    i == PP_NSTAMP - 2 ? dclk : (i == PP_NSTAMP - 1 ? drt :  // shader cycles and 100-MHz ticks of the main loop
+                    (i >= PP_NSTAMP - 10 && i < PP_NSTAMP - 2) ? (unsigned)seg_sum[i - (PP_NSTAMP - 10)] :
+                    (i < stamp_i ? *(__attribute__((address_space(3))) unsigned*)(lds + stamp_base + (wave * PP_NSTAMP + i) * 4) : 0u));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int CFG> struct Pp32Cfg;
+#define PP_NAS(a, b, c, d, e) ((a) | ((b) << 4) | ((c) << 8) | ((d) << 12) | ((e) << 16))
+// NAS: halo pieces per wave in the slots G0/0, G1/0, G0/1, G1/1, G0/2 (sum * 4 = igemm_fwd2's halo pieces per chunk: the same LDS budget)
+template <> struct Pp32Cfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+template <> struct Pp32Cfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NAS = PP_NAS(0, 4, 4, 2, 2), WP0 = 0; };
+template <> struct Pp32Cfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NAS = PP_NAS(0, 1, 2, 1, 2), WP0 = 0; };
+template <> struct Pp32Cfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+// (128x320 / 64x640, five pixel fragments per wave: measured 20-40 % slower than igemm_fwd2's -- three taps of fragments beside 80
+// accumulators leave no registers for the tile bookkeeping; not instantiated)
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG>
+static hipError_t pp32_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    auto kern = igemm_pp32_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG>;
+    const size_t lds = igemm_fwd2_lds_bytes(cfg, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+// strip widths an instantiation exists for: the halo tile must fit the DMA pieces of a chunk and the 16-bit offsets of the LDS reads
+constexpr bool pp32_geo_ok(int TM, int LSW, int NAS) {
+    const int SW = 1 << LSW, TR = TM >> LSW;
+    if (TR < 1 || TR * SW != TM) return false;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    int pieces = 0;
+    for (int k = 0; k < 5; ++k) pieces += pp_na_slot(NAS, k);
+    return NPIX <= pieces * 4 * 16 && NPIX * 64 + 2 * CW * 64 < 65536;
+}
+// the kernel is instantiated per strip width (2^LSW = 8 .. 64): the planner's geometry must be the one the instantiation assumes
+template <int WCO, int WPX, int CT, int PT, int NAS, int WP0, bool STAMP, bool DBG = false>
+static hipError_t pp32_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    constexpr int TM = WPX * PT * 16;
+    const int SW = 1 << p.lsw, TR = TM >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    if (p.dil != 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX || TR < 1) return hipErrorInvalidValue;
+    switch (p.lsw) {
+        case 3: if constexpr (pp32_geo_ok(TM, 3, NAS)) return pp32_launch_kernel2<WCO, WPX, CT, PT, 3, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 4: if constexpr (pp32_geo_ok(TM, 4, NAS)) return pp32_launch_kernel2<WCO, WPX, CT, PT, 4, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 5: if constexpr (pp32_geo_ok(TM, 5, NAS)) return pp32_launch_kernel2<WCO, WPX, CT, PT, 5, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+        case 6: if constexpr (pp32_geo_ok(TM, 6, NAS)) return pp32_launch_kernel2<WCO, WPX, CT, PT, 6, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
+    }
+    return hipErrorInvalidValue;
+}
+template <int CFG, bool STAMP = false, bool DBG = false>
+static hipError_t pp32_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
+    using C = Pp32Cfg<CFG>;
+    return pp32_launch_kernel<C::WCO, C::WPX, C::CT, C::PT, C::NAS, C::WP0, STAMP, DBG>(CFG, p, gx, st);
+}
+// (the five-fragment shapes are instantiated but lose: three taps of fragments beside 80 accumulators leave no room for the tile
+// bookkeeping, whose spills cost more than the lean loop gains; igemm_fwd2 keeps them)
+bool igemm_pp32_has(int cfg) { return cfg == IGF2_CFG_128x256 || cfg == IGF2_CFG_64x512 || cfg == IGF2_CFG_128x128 || cfg == IGF2_CFG_64x256; }
+// this launch, planned with this geometry, is one the ping-pong kernels are instantiated for (3x3 taps, stride 1, dilation 1, the
+// planner's halo tile for strip width 2^lsw)
+bool igemm_pp32_supports(int cfg, const IgFwdParams& p) {
+    if (!igemm_pp32_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
+    if (p.bits_out || p.bits_in) return false;   // the 1-bit ReLU masks (off by default) stay with igemm_fwd2
+    const int TM = igemm_fwd2_cfg_info(cfg).TM;
+    const int SW = 1 << p.lsw, TR = TM >> p.lsw;
+    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    if (TR < 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX) return false;
+    int nas = 0;
+    switch (cfg) {
+#define PP_CASE(C) case C: nas = Pp32Cfg<C>::NAS; break;
+        PP_CASE(IGF2_CFG_128x256) PP_CASE(IGF2_CFG_64x512) PP_CASE(IGF2_CFG_128x128) PP_CASE(IGF2_CFG_64x256)
+#undef PP_CASE
+    }
+    return pp32_geo_ok(TM, p.lsw, nas);
+}
+// 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
+hipError_t igemm_pp32_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
+    if ((p.dbg & 128) && p.stamps && cfg == IGF2_CFG_128x256) return pp32_launch_one<IGF2_CFG_128x256, true>(p, gx, st);   // time-stamping build
+    switch (cfg) {
+        case IGF2_CFG_128x256: return pp32_launch_one<IGF2_CFG_128x256>(p, gx, st);
+        case IGF2_CFG_64x512: return pp32_launch_one<IGF2_CFG_64x512>(p, gx, st);
+        case IGF2_CFG_128x128: return pp32_launch_one<IGF2_CFG_128x128>(p, gx, st);
+        case IGF2_CFG_64x256: return pp32_launch_one<IGF2_CFG_64x256>(p, gx, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -353,7 +353,9 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 
 // persistent conv launch of the chosen generation: the ping-pong kernel (igemm_pp.hip) runs the 3x3 stride-1 launches unless
 // RSU_FWD_GEN=2 asks for igemm_fwd2 (same tile shapes, same bits)
-static hipError_t launch_persistent(bool pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
+// (pp: 0 = igemm_fwd2, 1 = igemm_pp, 2 = igemm_pp32)
+static hipError_t launch_persistent(int pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
+    if (pp == 2 && igemm_pp32_supports(cfg, p)) return igemm_pp32_launch(cfg, p, gx, st);
     if (pp && igemm_pp_supports(cfg, p)) return igemm_pp_launch(cfg, p, gx, st);
     return igemm_fwd2_launch(cfg, ntap, p, gx, gy, st);
 }
@@ -387,7 +389,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
         return RSU_EINVAL;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
                                 (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (bits_out ? 8 : 0) | (bits_in ? 16 : 0),
-                                ostride, g_cu_budget.load() * 4 + gen};
+                                ostride, g_cu_budget.load() * 8 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
     bool tune_now = false;
     if (tunable) {
@@ -403,6 +405,26 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     if (!plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip)) {
         // a shape forced through RSU_FWD2_CFG whose halo tile does not fit this geometry: plan freely instead
         if (!(env_cfg >= 0 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip))) return RSU_EINVAL;
+    }
+    // RSU_FWD_GEN=5: igemm_pp32 wherever one of its shapes fits the launch -- a STATIC rule (its results differ from the other
+    // generations' in the last bits, so the choice between them must not hang on a timing); the tuner then picks among its shapes only
+    bool pp32 = false;
+    if (gen >= 5 && pp_ok && !bits_out && !bits_in) {
+        const int tn = igemm_fwd2_cfg_info(pl2.cfg).TN;
+        const int order[4] = {IGF2_CFG_128x256, IGF2_CFG_64x512, IGF2_CFG_128x128, IGF2_CFG_64x256};
+        for (int pass = 0; pass < 2 && !pp32; ++pass)
+            for (int k = 0; k < 4 && !pp32; ++k) {
+                const int cfg = pass == 0 ? (k == 0 ? pl2.cfg : -1) : order[k];
+                if (cfg < 0 || !igemm_pp32_has(cfg) || (pass == 1 && igemm_fwd2_cfg_info(cfg).TN != tn)) continue;
+                Fwd2Plan pc;
+                if (!plan_fwd2(pc, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
+                IgFwdParams pt;
+                memset(&pt, 0, sizeof(pt));
+                pt.stride = stride; pt.ostride = ostride; pt.dil = dil; pt.lsw = pc.lsw; pt.g = pc.g;
+                if (!igemm_pp32_supports(cfg, pt)) continue;
+                pl2 = pc;
+                pp32 = true;
+            }
     }
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -438,7 +460,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     {
         // kernel generation: the ping-pong kernel wherever it is instantiated (measured 10-20 % faster than igemm_fwd2 at every
         // shape; launch_persistent falls back to igemm_fwd2 for the rest) unless the tuner measured otherwise for this geometry
-        const bool pp = pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0);
+        const int pp = pp32 ? 2 : ((pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0)) ? 1 : 0);
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
@@ -473,7 +495,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             const hipEvent_t e0 = ev.a, e1 = ev.b;
             HIP_CHECK_RET(hipDeviceSynchronize());
             float best_ms = 1e30f, model_ms = 1e30f;
-            int best_cfg = pl2.cfg | ((pp ? 1 : 0) << 8);
+            int best_cfg = pl2.cfg | (pp << 8);
             const int model_code = best_cfg;
             for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
                 if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
@@ -483,13 +505,15 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                 pt.ncob = pc.ncob;
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
-                for (int vpp = 0; vpp < 2; ++vpp) {  // both kernel generations of the shape
-                    if (vpp && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
+                for (int vpp = 0; vpp < 3; ++vpp) {  // the kernel generations of the shape
+                    if (pp32 != (vpp == 2)) continue;   // igemm_pp32 launches tune among igemm_pp32 shapes only, the others never try it
+                    if (vpp == 2 && !igemm_pp32_supports(cfg, pt)) continue;
+                    if (vpp == 1 && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
                     if (!vpp && gen >= 4 && pp_ok && igemm_pp_supports(cfg, pt)) continue;
                     float ms_min = 1e30f;
                     for (int rep = 0; rep < 6; ++rep) {
                         HIP_CHECK_RET(hipEventRecord(e0, st));
-                        HIP_CHECK_RET(launch_persistent(vpp != 0, pc.cfg, ntap, pt, pc.grid_x, gy, st));
+                        HIP_CHECK_RET(launch_persistent(vpp, pc.cfg, ntap, pt, pc.grid_x, gy, st));
                         HIP_CHECK_RET(hipEventRecord(e1, st));
                         HIP_CHECK_RET(hipEventSynchronize(e1));
                         float ms = 0.f;

@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;  // one MFMA A/B fragm
 typedef __attribute__((ext_vector_type(4))) short bf16x4;  // one ds_read_b64_tr_b16 result
 typedef __attribute__((ext_vector_type(4))) float f32x4;   // one 16x16 accumulator tile slice
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // one 32x32 accumulator tile slice
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define RSU_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
@@ -65,6 +66,10 @@ __device__ __forceinline__ unsigned relu_mask_from_bits(unsigned b, int i) {
 // operand written by a VALU instruction followed by `s_nop 3` before the MFMA that reads it.
 __device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// the 32x32x16 form (igemm_pp32.hip): 16 accumulator registers per lane, 8 passes
+__device__ __forceinline__ void mfma32_bf16_inplace(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // XCD-aware workgroup numbering for one-workgroup-per-CU launches: the dispatcher deals consecutive workgroup ids round-robin over the 8
 // XCDs (id & 7), each with its own L2. This turns the hardware id into a logical id such that each XCD owns a CONTIGUOUS range of logical

@@ -16,8 +16,10 @@ from road_segmentation_unet_amd._lib import RsuSrc, call, lib  # noqa: E402
 from tests import hiputil as hu  # noqa: E402
 
 
-# (shape, RSU_FWD_GEN): 2 = igemm_fwd2, 4 = the ping-pong kernel igemm_pp wherever it is built (shapes 0-5; 6 and 7 fall back to igemm_fwd2)
-@pytest.fixture(params=[(c, g) for c in range(8) for g in (2, 4) if not (g == 4 and c >= 6)], ids=lambda cg: "cfg%d-gen%d" % cg)
+# (shape, RSU_FWD_GEN): 2 = igemm_fwd2, 4 = the ping-pong kernel igemm_pp wherever it is built (shapes 0-5; 6 and 7 fall back to igemm_fwd2),
+# 5 = igemm_pp32 (32x32x16 MFMAs; shapes 0-3)
+@pytest.fixture(params=[(c, g) for c in range(8) for g in (2, 4, 5) if not (g == 4 and c >= 6) and not (g == 5 and c >= 4)],
+                ids=lambda cg: "cfg%d-gen%d" % cg)
 def forced_cfg(request):
     old = {k: os.environ.get(k) for k in ("RSU_FWD2_CFG", "RSU_FWD_GEN")}
     os.environ["RSU_FWD2_CFG"] = str(request.param[0])

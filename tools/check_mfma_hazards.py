@@ -19,6 +19,7 @@ import re
 import sys
 
 RESULT_WS = 16   # required by the ISA for the 16x16x32 bf16 MFMA: <= 12
+RESULT_WS_32 = 20  # ... for the 32x32x16 form (8 passes of 4 cycles): <= 19
 OPERAND_WS = 3   # VALU write -> MFMA read: 2
 STORE_WS = 2     # wide VMEM store -> VALU overwrite of its data registers (see (3) below); documented: 1
 SGPR_WS = 5      # VALU write of an SGPR -> (inline-asm) VMEM instruction that reads it; documented: 5
@@ -181,7 +182,7 @@ def check(path):
                         bad += 1
                         return False
                     return True
-                walk(ins, labels, i, RESULT_WS, visit)
+                walk(ins, labels, i, RESULT_WS_32 if "32x32" in I.text else RESULT_WS, visit)
             else:
                 sd = I.wide_store_data()
                 if sd:

@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 H=$1; CIN=$2; COUT=$3; OP=${4:-fwd}
 cd /tmp && export TMPDIR=/tmp
 export RSU_AUTOTUNE=0 RSU_FWD2_CFG=0
-for G in 2 4; do
+for G in ${GENS:-2 4}; do
   export RSU_FWD_GEN=$G
   OUT=$REPO/gpurun_out/pmc_gen$G
   rm -rf $OUT; mkdir -p $OUT
@@ -15,7 +15,7 @@ done
 python3 - <<PY
 import csv, glob, collections
 rows = []
-for G in (2, 4):
+for G in tuple(int(x) for x in "${GENS:-2 4}".split()):
     OUT = "$REPO/gpurun_out/pmc_gen%d" % G
     dur = collections.defaultdict(list)
     for f in glob.glob(OUT + "/**/p1_kernel_trace.csv", recursive=True) + glob.glob(OUT + "/p1_kernel_trace.csv"):
@@ -36,8 +36,9 @@ for G in (2, 4):
                      "%.3f" % (c.get("SQ_INSTS_VMEM", 0) / mf if mf else 0),
                      "%.3f" % (c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else 0),
                      "%.2f" % ghz,
-                     "%.3f" % (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * us * 1e3 * ghz) if us and ghz else 0)])
-hdr = "kernel,us_under_pmc,MFMA_insts,nonMFMA_VALU_per_MFMA,SALU_per_MFMA,LDS_insts_per_MFMA,VMEM_insts_per_MFMA,WAIT_ANY_frac_of_wave_cycles,clock_GHz_GRBM,mfma_pipe_util_at_that_clock"
+                     "%.3f" % (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * us * 1e3 * ghz) if us and ghz else 0),
+                     "%.3f" % (c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else 0)])
+hdr = "kernel,us_under_pmc,MFMA_insts,nonMFMA_VALU_per_MFMA,SALU_per_MFMA,LDS_insts_per_MFMA,VMEM_insts_per_MFMA,WAIT_ANY_frac_of_wave_cycles,clock_GHz_GRBM,mfma_pipe_util_at_that_clock,lds_bank_conflict_per_active_cycle"
 open("$REPO/gpurun_out/pmc_gen_ab.csv", "w").write(hdr + "\n" + "\n".join(",".join(map(str, r)) for r in rows) + "\n")
 print(hdr)
 for r in rows:
