@@ -489,27 +489,20 @@ igemm_pp32_kernel(const IgFwdParams p) {
     // the loop; a tile starts them at the bias and ends with its epilogue, which opens the wave's next R interval.
     f32x16 acc[CT2][PT2];
     // every accumulator starts at the bias of its rows (register 4 j + i of a lane = row 8 j + 4 h32 + i = channel 8 h32 + i (j = 0),
-    // 16 + 8 h32 + i (j = 1), 8 h32 + 4 + i (j = 2), 16 + 8 h32 + 4 + i (j = 3) of the 32-channel group). Done for the first tile in
-    // front of the loop and for every other tile right behind the previous tile's epilogue, in the interval both groups spend on
-    // their epilogues with no MFMAs beside them (vector moves are cheap there; beside an MFMA stream each costs ~17 cycles)
+    // 16 + 8 h32 + i (j = 1), 8 h32 + 4 + i (j = 2), 16 + 8 h32 + 4 + i (j = 3) of the 32-channel group), read from LDS in the first R
+    // interval of the tile as in igemm_pp
     auto init_acc = [&]() {
 #pragma unroll
         for (int c2 = 0; c2 < CT2; ++c2) {
             const __attribute__((address_space(3))) float* bp = (const __attribute__((address_space(3))) float*)(lds + bias_base) + (wco * CT2 + c2) * 32 + 8 * h32;
-            const f32x4 b0 = *(const __attribute__((address_space(3))) f32x4*)(bp), b1 = *(const __attribute__((address_space(3))) f32x4*)(bp + 16),
-                        b2 = *(const __attribute__((address_space(3))) f32x4*)(bp + 4), b3 = *(const __attribute__((address_space(3))) f32x4*)(bp + 20);
-            f32x16 t;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                t[i] = b0[i];
-                t[4 + i] = b1[i];
-                t[8 + i] = b2[i];
-                t[12 + i] = b3[i];
-            }
 #pragma unroll
             for (int p2 = 0; p2 < PT2; ++p2) {
-                acc[c2][p2] = t;
-                asm volatile("" : "+v"(acc[c2][p2]));
+                // (four 16-byte LDS reads per accumulator, straight into its registers: no vector moves)
+                const f32x4 b0 = *(const volatile __attribute__((address_space(3))) f32x4*)(bp), b1 = *(const volatile __attribute__((address_space(3))) f32x4*)(bp + 16),
+                            b2 = *(const volatile __attribute__((address_space(3))) f32x4*)(bp + 4), b3 = *(const volatile __attribute__((address_space(3))) f32x4*)(bp + 20);
+                const __attribute__((ext_vector_type(8))) float lo = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const __attribute__((ext_vector_type(8))) float hi = __builtin_shufflevector(b2, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[c2][p2] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
             }
         }
     };
@@ -519,10 +512,10 @@ igemm_pp32_kernel(const IgFwdParams p) {
         int ck = 0;              // current tile
         Pos cpos = split(tile0);
         Tile ctile = tile_at(cpos);
-        init_acc();
         auto chunk = [&](auto parc, int gc) {
             constexpr int PAR = decltype(parc)::value;
             seg_begin();
+            if (c == 0 && !(DBG && (p.dbg & 16))) init_acc();   // (16 LDS reads; they land before the s_waitcnt lgkmcnt(0) that ends this R interval)
             seg_end(2);
             const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
             auto phase = [&](auto jc) {
@@ -613,8 +606,7 @@ igemm_pp32_kernel(const IgFwdParams p) {
                 seg_begin();
                 if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
                 seg_end(0);
-                if (!(DBG && (p.dbg & 16))) init_acc();   // the next tile's accumulators (dbg bit 4: timing without)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
                 bar();
                 if constexpr (G == 1) bar();
                 c = 0;
