@@ -225,6 +225,10 @@ int main() {
             run<5, 16, 8, 12, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 12 VALU + 24 SALU", 512, blocks, src, out, cyc);
             run<5, 16, 8, 4, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 4 VALU + 8 SALU", 512, blocks, src, out, cyc);
             run<5, 16, 8, 4, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 4 VALU + 8 SALU", 512, blocks, src, out, cyc);
+            run<4, 16, 8, 2, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 2 LDS-DMA", 512, blocks, src, out, cyc);
+            run<4, 16, 8, 2, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 2 LDS-DMA", 512, blocks, src, out, cyc);
+            run<4, 16, 8, 4, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 4 LDS-DMA", 512, blocks, src, out, cyc);
+            run<4, 16, 8, 4, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 4 LDS-DMA", 512, blocks, src, out, cyc);
         }
         return 0;
     }
