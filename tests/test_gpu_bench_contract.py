@@ -50,5 +50,5 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0.5 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     ex = d["config"]["dp_exchange"]
-    assert ex["conv_cu_budget"] in (256, 240, 224, 208) and len(ex["tuned_ms_per_step"]) == 6 and ex["min_bucket_MB"] in (4, 32)
+    assert ex["backward_cu_budget"] in (256, 240, 224, 208) and len(ex["tuned_ms_per_step"]) == 6 and ex["min_bucket_MB"] in (4, 32)
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None or d["cpu_baseline"]
