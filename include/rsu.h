@@ -10,11 +10,13 @@
  * Conventions
  *   - plain C: device pointers + sizes, no torch / C++ types. `stream` is a hipStream_t passed
  *     as void* (NULL = the default stream). All calls are asynchronous on that stream and
- *     re-entrant per stream. Process-wide state (all of it advisory, none of it changes a result): the CU budget
- *     (rsu_set_cu_budget), the tile-shape tuning switch and its table of measured choices (rsu_set_autotune; the FIRST call of
- *     a new conv geometry synchronises the device and times the candidate shapes), and one page of zeros per device.
+ *     re-entrant per stream. Every MFMA launch takes the compute units it may plan for as its own `ncu` argument; nothing has
+ *     to be set between launches. Process-wide state (advisory, none of it changes a result): the DEFAULT budget behind ncu = 0
+ *     (rsu_set_cu_budget), the tile-shape tuning mode and its table of measured choices (rsu_set_autotune: launches look shapes
+ *     up and never measure unless the host switches to RSU_TUNE_MEASURE for an explicit tuning pass), one page of zeros per device.
  *   - devices: one process drives one GPU (torch.distributed, one rank per device). The HIP current device must be the device
- *     the stream and the pointers belong to (the Python host calls torch.cuda.set_device); tensors stay below 2 GiB each.
+ *     the stream and the pointers belong to (the Python host calls torch.cuda.set_device); tensors stay below 2 GiB each
+ *     (RSU_E2BIG otherwise: split the batch).
  *   - activations: NHWC, bfloat16 ("bf16", the storage type of the fast path), raw uint16 bits.
  *     Channel counts of bf16 tensors must be multiples of 8 (16-byte pieces).
  *   - parameters / gradients / optimizer state: float32 in the reference's own layouts: conv
@@ -38,6 +40,7 @@ extern "C" {
 #define RSU_EINVAL (-22)  /* bad geometry / unsupported shape (the reference raises AssertionError) */
 #define RSU_ENOMEM (-12)  /* workspace too small */
 #define RSU_EHIP (-5)     /* a HIP runtime call failed; see rsu_last_hip_error() */
+#define RSU_E2BIG (-7)    /* a tensor of this call reaches 2 GiB (32-bit byte offsets inside the kernels): use a smaller batch */
 
 typedef void* rsu_stream_t; /* hipStream_t */
 
@@ -54,23 +57,33 @@ typedef struct {
 /* ---- library / device ------------------------------------------------------------------- */
 const char* rsu_version(void);
 int rsu_last_hip_error(void);
-/* Compute units the persistent conv launches plan for (32..256, default 256 = the whole MI355X). New here (the reference is
- * single-device). The value is read when a launch is planned, so a single-threaded host may change it from launch to launch:
- * a data-parallel host leaves some CUs to the RCCL channel workgroups of an overlapped gradient all-reduce, and the Python host
- * (unet.py, RSU_SPLIT_CHIP) plans the backward-data launches of its main stream and the weight-gradient launches of its side
- * stream for disjoint halves of the chip, so that one kernel of each kind is resident at a time. For the weight gradients the
- * budget sets the number of partial sums per output tile: it changes their summation order (results agree to fp32 rounding),
- * for every other launch it only changes speed. */
+/* Compute units a persistent MFMA launch plans for (one workgroup each). New here (the reference is single-device). Every
+ * MFMA entry point below takes it as its `ncu` argument, 32..256 (256 = the whole MI355X); ncu = 0 selects the process default
+ * set here (256 unless changed). A data-parallel host leaves some CUs to the RCCL channel workgroups of an overlapped gradient
+ * all-reduce; the Python host (unet.py, RSU_SPLIT_CHIP) gives the backward-data launches of its main stream and the
+ * weight-gradient launches of its side stream disjoint shares of the chip, so that one kernel of each kind is resident at a
+ * time. For the weight gradients ncu sets the number of partial sums per output tile: it changes their summation order
+ * (results agree to fp32 rounding); for every other launch it only changes speed. */
 int rsu_set_cu_budget(int ncu);
 int rsu_get_cu_budget(void);
-/* Tile-shape choice of the conv launches by measurement (default on; RSU_AUTOTUNE=0 in the environment also disables it): the
- * first launch of a new geometry times every admissible tile shape on an idle device (it synchronises the device once) and
- * later launches of that geometry use the fastest (if it beats the cost model's choice by 3 %). All shapes give bit-identical results. rsu_autotune_entries: geometries
- * tuned so far. */
-int rsu_set_autotune(int on);
+/* Tile shapes of the conv launches by measurement. All shapes give bit-identical results; the mode only moves time.
+ *   RSU_TUNE_OFF      the cost model decides (RSU_AUTOTUNE=0 in the environment forces this);
+ *   RSU_TUNE_LOOKUP   (default) a launch uses the measured shape of its (geometry, flags, ncu) if the table holds one, else the
+ *                     model's; it never measures, so the launch entry points never synchronise the device;
+ *   RSU_TUNE_MEASURE  a launch whose key is missing times every admissible shape on an idle device (synchronises it) and keeps
+ *                     the fastest if it beats the model's choice by 3 %. The host switches this on around ONE explicit, untimed
+ *                     pass over its network (UNet.tune) -- under data parallelism before any collective is in flight.
+ * rsu_autotune_entries: geometries measured so far. */
+#define RSU_TUNE_OFF 0
+#define RSU_TUNE_LOOKUP 1
+#define RSU_TUNE_MEASURE 2
+int rsu_set_autotune(int mode);
+int rsu_get_autotune(void);
 int rsu_autotune_entries(void);
 /* The table of measured choices as rows of 17 ints (opaque key words + choice): export after a run, import before another (a
- * profiling run then issues no timing launches). export returns the number of entries (rows may be NULL to count). */
+ * profiling run then issues no timing launches). export returns the number of entries (rows may be NULL to count); import
+ * returns the number of rows it took: rows naming a tile shape or kernel generation this build does not have are skipped (the
+ * host also stamps its file with the library's hash, bench.py). */
 int rsu_autotune_export(int* rows, int capacity);
 int rsu_autotune_import(const int* rows, int nrows);
 /* unet.py:100-115 input_size_needed(output_size, num_layers). RSU_EINVAL where the reference asserts. */
@@ -123,7 +136,7 @@ int rsu_color_adjust_fwd(const float* x, const float* w, const float* b, void* o
 size_t rsu_packed_first_bytes(int Cout);
 int rsu_pack_conv_first(const float* w_hwio, void* packed, int Cout, rsu_stream_t stream);
 int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout,
-                       int dil, rsu_stream_t stream);
+                       int dil, int ncu, rsu_stream_t stream);
 /* weight/bias gradients of that conv and, through it, of color_space_adjust (no input-gradient pass is needed):
  * dw1 [3][3][3][Cout]; gx [9][12][Cout]: rows 0..8 gxc[t][3*ci+cj][co] = sum_pix m[pix+t][cj] (x-0.5)[pix+t][ci] dz[pix][co],
  * rows 9..11 gm[t][cj][co] = sum_pix m[pix+t][cj] dz[pix][co]. With W1 = this conv's kernel:
@@ -133,7 +146,7 @@ int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, voi
 size_t rsu_conv_first_bwd_ws_floats(int Cout);
 /* db (optional): BiasAddGrad of this conv, computed by the same launch */
 int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gx, float* db, float* ws, int N,
-                              int H, int W, int Cout, int dil, rsu_stream_t stream);
+                              int H, int W, int Cout, int dil, int ncu, rsu_stream_t stream);
 /* The two sums above in one launch: dW0 f32 [3][3] ([ci][cj]) and db0 f32 [3] from gx [9][12][Cout] and W1 f32 HWIO
  * [3][3][3][Cout]; scale = 1/keep. accumulate != 0 adds to dW0/db0 (the dilated twin conv_dilut_0 shares color_space_adjust). */
 int rsu_color_adjust_bwd(const float* gx, const float* w1, float* dW0, float* db0, int Cout, float scale, int accumulate,
@@ -156,25 +169,14 @@ int rsu_head_fwd_bwd(const void* act, const float* w, const float* b, const int6
 /* unet.py:34-39,42-45,88-91: y = relu(conv3x3_valid(concat(srcs), W, dilation) + b).
  * All sources share the window size (Hin, Win); y is bf16 [N][Hin-2d][Win-2d][Cout]. */
 int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
-                   int Hin, int Win, int Cout, int dil, int relu, rsu_stream_t stream);
+                   int Hin, int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream);
 /* Conv2DBackpropInput for input channels [ci_off, ci_off+ci_cnt) of a conv with Cin_total inputs:
  * dx bf16 [N][H][W][ci_cnt] (H, W = conv input size), dz bf16 [N][H-2d][W-2d][Cout].
  * relu_src (optional, same shape as dx): dx *= (relu_src > 0)  -- ReluGrad of the producing layer.
  * accumulate != 0: dx += result (two consumers of one tensor, unet.py:32-45). */
 int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate,
-                        int N, int H, int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil,
+                        int N, int H, int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu,
                         rsu_stream_t stream);
-/* 1-bit ReLU masks (new; TensorFlow keeps the whole activation for ReluGrad). The forward conv can emit, beside y, one bit per element
- * (y > 0): relu_bits uint8 [N][Ho][Wo][Cout/8], bit k of byte j = channel 8j+k (rsu_relu_bits_bytes bytes, < 128 MiB). Backward-data
- * of the NEXT conv then takes these bits as its ReluGrad mask instead of re-reading the bf16 activation (16x fewer bytes):
- * rsu_conv2d_bwd_data_bits == rsu_conv2d_bwd_data(relu_src = y, accumulate = 0, ci_off = 0, ci_cnt = Cin_total), bit for bit. */
-size_t rsu_relu_bits_bytes(int N, int H, int W, int C);
-int rsu_conv2d_fwd_bits(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* relu_bits, int N,
-                        int Hin, int Win, int Cout, int dil, rsu_stream_t stream);
-int rsu_conv_first_fwd_bits(const void* in16, const void* packed, const float* b, void* y, void* relu_bits, int N, int H, int W,
-                            int Cout, int dil, rsu_stream_t stream);
-int rsu_conv2d_bwd_data_bits(const void* dz, const void* packed_bwd, void* dx, const void* relu_bits, int N, int H, int W,
-                             int Cin_total, int Cout, int dil, rsu_stream_t stream);
 /* Conv2DBackpropFilter for the input channels held by `src` (rows [ci_off, ci_off+src.C) of dw):
  * dw f32 HWIO [3][3][Cin_total][Cout] (only those rows are written). (Ho, Wo) = size of dz.
  * ws: rsu_conv2d_bwd_weight_ws_floats() floats of scratch (split-K slabs). */
@@ -182,7 +184,7 @@ size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout);
 /* db (optional, f32 [Cout]): BiasAddGrad = sum over pixels of dz, computed by the same launch (one extra MFMA per
  * 32-pixel step); pass it with ONE of the sources of a concatenated input, NULL with the others. */
 int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
-                          int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream);
+                          int Cin_total, int ci_off, int Cout, int dil, int ncu, rsu_stream_t stream);
 /* BiasAddGrad: db[c] = sum over npix of dz[pix][c]. ws: rsu_bias_grad_ws_floats(npix, C) floats. */
 size_t rsu_bias_grad_ws_floats(long npix, int C);
 int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_stream_t stream);
@@ -215,15 +217,15 @@ int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsigned key, rs
 
 /* ---- 2x2 stride-2 transposed convolution (unet.py:67-68) ---------------------------------- */
 int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W,
-                     int Cin, int Cout, rsu_stream_t stream);
+                     int Cin, int Cout, int ncu, rsu_stream_t stream);
 /* dx bf16 [N][H][W][Cin] = out_scale * sum_{a,b,co} dy[2i+a][2j+b][co] K[a][b][co][ci], times (relu_src > 0) if given */
 int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, float out_scale,
-                          int N, int H, int W, int Cin, int Cout, rsu_stream_t stream);
+                          int N, int H, int W, int Cin, int Cout, int ncu, rsu_stream_t stream);
 /* dK f32 [2][2][Cout][Cin] and, when db != NULL, db f32 [Cout] = sum over all pixels of dy (BiasAddGrad of the transposed
  * conv, unet.py:72) from the same launch; ws: rsu_convT2x2_bwd_weight_ws_floats() floats */
 size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout);
 int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W,
-                            int Cin, int Cout, rsu_stream_t stream);
+                            int Cin, int Cout, int ncu, rsu_stream_t stream);
 
 /* ---- optimizer (tf_aerial_images.py:116-121, MomentumOptimizer, use_nesterov=False) ------- */
 /* acc = mu*acc + gscale*g ; w -= lr*acc. gscale folds the 1/world_size of data-parallel averaging. */
@@ -245,7 +247,8 @@ int rsu_overlap_finish(const float* acc, const float* hits, float* out, long n, 
 
 /* ---- post-processing wire format (src/images.py) and metric counters (src/summary.py) ------ */
 /* images.py:256-266 quantize_mask: per patch_size block of masks f32 [nimg][S][S] (channel axis squeezed), label =
- * mean(mask >= 0.5) > threshold, written over the block of `out` (may alias masks). patch_size <= 64. */
+ * mean(mask >= 0.5) > threshold, written over the block of `out` (out == masks is allowed: a block is read completely before it
+ * is written). patch_size <= 64. */
 int rsu_quantize_mask(const float* masks, float* out, int nimg, int S, int patch_size, float threshold, rsu_stream_t stream);
 /* images.py:88-99 labels_for_patches over images.py:35-85 extract_patches(masks, patch_size): labels int64
  * [nimg][S/ps][S/ps] in the reference's patch order (x outer, y inner), label = mean(patch) > threshold. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "rsu_set_cu_budget": (_i, [_i]),
     "rsu_get_cu_budget": (_i, []),
     "rsu_set_autotune": (_i, [_i]),
+    "rsu_get_autotune": (_i, []),
     "rsu_autotune_entries": (_i, []),
     "rsu_autotune_export": (_i, [_PI, _i]),
     "rsu_autotune_import": (_i, [_PI, _i]),
@@ -53,31 +54,27 @@ SIGNATURES = {
     "rsu_dropout_fwd": (_i, [_vp, _vp, _l, _f, _u, _vp]),
     "rsu_packed_first_bytes": (_sz, [_i]),
     "rsu_pack_conv_first": (_i, [_vp, _vp, _i, _vp]),
-    "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv_first_bwd_ws_floats": (_sz, [_i]),
-    "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_color_adjust_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "rsu_head_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     "rsu_head_ws_floats": (_sz, [_l, _i]),
     "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
-    "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "rsu_relu_bits_bytes": (_sz, [_i, _i, _i, _i]),
-    "rsu_conv2d_fwd_bits": (_i, [_PS, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsu_conv_first_fwd_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsu_conv2d_bwd_data_bits": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
-    "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
     "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_maxpool2x2_fwd_code": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_pool_skip_relu_bwd_code": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u, _vp]),
     "rsu_pool_skip_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u, _vp]),
-    "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_data": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_convT2x2_bwd_weight_ws_floats": (_sz, [_i, _i]),
-    "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_momentum_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _l, _vp]),
     "rsu_extract_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
@@ -111,7 +108,14 @@ def lib():
     return _lib
 
 
+TUNE_OFF, TUNE_LOOKUP, TUNE_MEASURE = 0, 1, 2   # rsu.h RSU_TUNE_*
+E2BIG = -7
+
+
 def check(rc, what):
+    if rc == E2BIG:
+        raise RsuError("%s: a tensor of this call reaches 2 GiB (the kernels address tensors through 32-bit byte offsets): "
+                       "use a smaller per-GPU batch" % what)
     if rc != 0:
         raise RsuError("%s failed: rc=%d (hip error %d)" % (what, rc, lib().rsu_last_hip_error()))
 

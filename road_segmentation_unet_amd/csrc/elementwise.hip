@@ -819,7 +819,9 @@ hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, lo
 //   mode 1 (labels_for_patches, images.py:88-99):    label = mean(mask) > threshold, written to labels[img][bx][by] (x outer: the
 //                                                    patch order of extract_patches) as int64
 // Blocks cut by the image edge average over the pixels they hold (numpy slicing does the same).
-__global__ void __launch_bounds__(256) k_block_label(const float* __restrict__ mask, float* __restrict__ out, int64_t* __restrict__ labels,
+// (mask and out may be the SAME buffer -- quantize_mask in place, rsu.h: no __restrict__ on them; a block's stores follow the barrier of
+// its reduction, and blocks do not overlap)
+__global__ void __launch_bounds__(256) k_block_label(const float* mask, float* out, int64_t* __restrict__ labels,
                                                      int S, int ps, int nb, float thr, int mode) {
     const int b = blockIdx.x, by = b % nb, bx = (b / nb) % nb, img = b / (nb * nb);
     const int y0 = by * ps, x0 = bx * ps;

@@ -26,9 +26,6 @@ struct IgFwdParams {
     const float* bias;    // [Cout] or null
     bf16_t* out;          // [N][oH][oW][outC]
     const bf16_t* mask_src;  // same geometry as out, or null
-    unsigned char* bits_out;       // forward with ReLU: 1-bit "> 0" mask of out, [N][oH][oW][outC/8] bytes, or null
-    const unsigned char* bits_in;  // backward-data: that mask instead of mask_src (never both), or null
-    unsigned bits_bytes;           // size of the mask tensor (range check of the byte accesses; < 2^27)
     const void* zero_page;   // >= 64 zero bytes
     int N, Hin, Win;      // logical input window
     int Ho, Wo;           // output pixel grid of the GEMM (before output scatter)
@@ -56,10 +53,6 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
 bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
-// fourth generation (igemm_pp32.hip): igemm_pp with 32x32x16 MFMAs; results equal to fp32 rounding, not bit for bit
-hipError_t igemm_pp32_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
-bool igemm_pp32_has(int cfg);
-bool igemm_pp32_supports(int cfg, const IgFwdParams& p);
 
 // ---------------------------------------------------------------------------------------------
 // igemm_ct (igemm_ct.hip): the 2x2 stride-2 transposed convolution as a ping-pong GEMM over the low-resolution pixels m = (n, y, x)

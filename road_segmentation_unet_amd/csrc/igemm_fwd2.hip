@@ -260,19 +260,14 @@ igemm_fwd2_kernel(const IgFwdParams p) {
             unsigned ones_pk = 0x00010001u;
             asm volatile("" : "+v"(ones_pk));
             constexpr int MB = NST % 4 == 0 ? 4 : 2;
-            const bool anybits = p.bits_out || p.bits_in;
-            const __amdgpu_buffer_rsrc_t brsrc =
-                __builtin_amdgcn_make_buffer_rsrc(p.bits_out ? (void*)p.bits_out : (void*)p.bits_in, 0, anybits ? (int)p.bits_bytes : 0, 0x00020000);
 #pragma unroll
             for (int b0 = 0; b0 < NST; b0 += MB) {
                 unsigned voffs[MB];
                 u32x4 mk4[MB];
-                unsigned mbits[MB];
 #pragma unroll
                 for (int e = 0; e < MB; ++e) {
                     voffs[e] = out_voff(T, b0 + e);
                     if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
-                    if (p.bits_in) mbits[e] = __builtin_amdgcn_raw_buffer_load_b8(brsrc, voffs[e] >> 4, sbase >> 4, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < MB; ++e) {
@@ -289,16 +284,9 @@ igemm_fwd2_kernel(const IgFwdParams p) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) r[i] &= pos_mask_pk_bf16(mk4[e][i], ones_pk);
                     }
-                    if (p.bits_in) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r[i] &= relu_mask_from_bits(mbits[e], i);
-                    }
-                    // (the byte store of the 1-bit mask is one more VMEM operation per store: the counted waits behind an epilogue then
-                    // allow fewer loads in flight than are there -- they wait a little longer, never too short)
-                    if (p.bits_out) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)relu_bits_pk(r, ones_pk), brsrc, voffs[e] >> 4, sbase >> 4, 0);
                     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(voffs[e]), "s"(orsrc), "s"(sbase) : "memory");
                 }
-                if (p.mask_src || p.bits_in) __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
+                if (p.mask_src) __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
             }
             return;
         }

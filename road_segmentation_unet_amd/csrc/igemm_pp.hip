@@ -706,7 +706,6 @@ bool igemm_pp_has(int cfg) { return cfg >= 0 && cfg < IGF2_NCFG && cfg != IGF2_C
 // planner's halo tile for strip width 2^lsw)
 bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
     if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
-    if (p.bits_out || p.bits_in) return false;   // the 1-bit ReLU masks (off by default) stay with igemm_fwd2
     const int TM = igemm_fwd2_cfg_info(cfg).TM;
     const int SW = 1 << p.lsw, TR = TM >> p.lsw;
     const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
@@ -723,6 +722,7 @@ bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
 // 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
+#ifdef RSU_DEV_KERNELS   // developer build only (make DEV=1 -> build_ab/): the time-stamping and timing-ablation instantiations
     if ((p.dbg & 128) && p.stamps) {  // diagnostic build with interval time stamps
         if (cfg == IGF2_CFG_128x256 && (p.dbg & ~128)) return pp_launch_one<IGF2_CFG_128x256, true, true>(p, gx, st);
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, true>(p, gx, st);
@@ -732,6 +732,7 @@ hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st
         if (cfg == IGF2_CFG_128x256) return pp_launch_one<IGF2_CFG_128x256, false, true>(p, gx, st);
         if (cfg == IGF2_CFG_64x512) return pp_launch_one<IGF2_CFG_64x512, false, true>(p, gx, st);
     }
+#endif
     switch (cfg) {
         case IGF2_CFG_128x256: return pp_launch_one<IGF2_CFG_128x256>(p, gx, st);
         case IGF2_CFG_64x512: return pp_launch_one<IGF2_CFG_64x512>(p, gx, st);

@@ -700,6 +700,7 @@ bool igemm_wgpp_supports(int cfg, int ntap, const IgWgradParams& p) {
            2 * (2 * 128 * 128 + NSW * 8 * 1024) <= 160 * 1024;
 }
 hipError_t igemm_wgpp_launch(const IgWgradParams& p, int gx, int gy, int gz, hipStream_t st) {
+#ifdef RSU_DEV_KERNELS   // developer build only (make DEV=1 -> build_ab/)
     if (p.dbg) {  // timing ablations / schedule variants (strip width 16 and 32 only): RSU_WG_DBG = 16 * SCH + DBG
 #define WGPP_CASE(L, S, D) if (p.lsw == L && p.dbg == 16 * S + D) return wgpp_launch_one<L, D, S>(p, gx, gy, gz, st)
 #define WGPP_CASES(L, S) WGPP_CASE(L, S, 0); WGPP_CASE(L, S, 1); WGPP_CASE(L, S, 2); WGPP_CASE(L, S, 3); WGPP_CASE(L, S, 4); WGPP_CASE(L, S, 5); WGPP_CASE(L, S, 7); WGPP_CASE(L, S, 9)
@@ -707,6 +708,7 @@ hipError_t igemm_wgpp_launch(const IgWgradParams& p, int gx, int gy, int gz, hip
 #undef WGPP_CASES
 #undef WGPP_CASE
     }
+#endif
     switch (p.lsw) {
         case 3: return wgpp_launch_one<3>(p, gx, gy, gz, st);
         case 4: return wgpp_launch_one<4>(p, gx, gy, gz, st);

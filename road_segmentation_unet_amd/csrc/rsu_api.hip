@@ -41,8 +41,9 @@ static inline int env_int(const char* name, int dflt) {
 
 extern "C" const char* rsu_version(void) { return "rsu-hip 0.1 (gfx950)"; }
 extern "C" int rsu_last_hip_error(void) { return g_last_hip_error.load(); }
-// CUs the persistent conv launches plan for (one workgroup each). 256 = the whole chip; a data-parallel run may leave a few to
-// RCCL's channel workgroups, which cannot share a CU with a persistent workgroup (dist.py picks the value by measurement)
+// CUs the persistent conv launches plan for (one workgroup each). Every MFMA entry point takes the number as its `ncu` argument
+// (32..256); ncu = 0 means this process-wide DEFAULT (256 = the whole chip; tests lower it to run every op at another budget). The
+// host never has to change the default between launches: unet.py passes the share of each stream with the launch.
 static std::atomic<int> g_cu_budget{256};
 extern "C" int rsu_set_cu_budget(int ncu) {
     if (ncu < 32 || ncu > 256) return RSU_EINVAL;
@@ -50,17 +51,27 @@ extern "C" int rsu_set_cu_budget(int ncu) {
     return RSU_OK;
 }
 extern "C" int rsu_get_cu_budget(void) { return g_cu_budget.load(); }
+// the budget of one launch: its own argument, or the default; -1 = invalid
+static int launch_ncu(int ncu) {
+    if (ncu == 0) return g_cu_budget.load();
+    return (ncu < 32 || ncu > 256) ? -1 : ncu;
+}
 // Tile-shape choice of the persistent conv launches by measurement. Every shape computes bit-identical results (the reduction
 // order of an output element does not depend on the tile it lies in; tests/test_gpu_cfg_matrix.py), so the choice only affects
-// speed. With tuning on, the first launch of a new (geometry, flags, CU budget) times every admissible shape on an idle device
-// and remembers the fastest; later launches look it up. Off: the planner's cost model decides (as does RSU_FWD2_CFG >= 0).
-static std::atomic<int> g_autotune{1};
+// speed. Modes (rsu_set_autotune): RSU_TUNE_OFF the planner's cost model decides (as does RSU_FWD2_CFG >= 0); RSU_TUNE_LOOKUP (the
+// default) a launch uses the measured shape of its (geometry, flags, CU budget) when the table holds one and NEVER measures -- the
+// launch entry points stay asynchronous; RSU_TUNE_MEASURE a launch whose key is missing times every admissible shape on an idle
+// device (it synchronises the device) and records the fastest: the host switches this on for one explicit, untimed tuning pass
+// (UNet.tune) and back to LOOKUP afterwards.
+static std::atomic<int> g_autotune{RSU_TUNE_LOOKUP};
 static std::mutex g_tune_mutex;
 static std::map<std::array<int, 16>, int> g_tuned;
-extern "C" int rsu_set_autotune(int on) {
-    g_autotune.store(on ? 1 : 0);
+extern "C" int rsu_set_autotune(int mode) {
+    if (mode < RSU_TUNE_OFF || mode > RSU_TUNE_MEASURE) return RSU_EINVAL;
+    g_autotune.store(mode);
     return RSU_OK;
 }
+extern "C" int rsu_get_autotune(void) { return g_autotune.load(); }
 extern "C" int rsu_autotune_entries(void) {
     std::lock_guard<std::mutex> lk(g_tune_mutex);
     return (int)g_tuned.size();
@@ -80,15 +91,22 @@ extern "C" int rsu_autotune_export(int* rows, int capacity) {
     }
     return n;
 }
+// rows whose choice word does not name a live tile shape and kernel generation of THIS build (a table exported by another build)
+// are skipped; returns the number of rows taken
 extern "C" int rsu_autotune_import(const int* rows, int nrows) {
     if (!rows || nrows < 0) return RSU_EINVAL;
     std::lock_guard<std::mutex> lk(g_tune_mutex);
+    int taken = 0;
     for (int r = 0; r < nrows; ++r) {
+        const int choice = rows[r * 17 + 16], shape = choice & 255, gen = choice >> 8;
+        if (choice < 0 || shape >= IGF2_NCFG || igemm_fwd2_cfg_info(shape).TN == 0 || gen < 0 || gen > 1) continue;
+        if (gen == 1 && !igemm_pp_has(shape)) continue;
         std::array<int, 16> k;
         for (int i = 0; i < 16; ++i) k[i] = rows[r * 17 + i];
-        g_tuned[k] = rows[r * 17 + 16];
+        g_tuned[k] = choice;
+        ++taken;
     }
-    return RSU_OK;
+    return taken;
 }
 
 extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input_size) {
@@ -296,7 +314,7 @@ extern "C" int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsig
 // ---------------------------------------------------------------------------------------------
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
 struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
-static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
+static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
                       int force_cfg, bool shared_chip = false) {
     double best_cost = 1e300;
     bool have = false;
@@ -320,7 +338,7 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
         if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
         const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
-        long workers = g_cu_budget.load() / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
+        long workers = ncu / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
         if (workers < 1) workers = 1;
         if (workers > ntile_m) workers = ntile_m;
         const long rounds = (ntile_m + workers - 1) / workers;
@@ -353,43 +371,38 @@ static bool plan_fwd2(Fwd2Plan& best, int N, int Ho, int Wo, int Cout, int ntap,
 
 // persistent conv launch of the chosen generation: the ping-pong kernel (igemm_pp.hip) runs the 3x3 stride-1 launches unless
 // RSU_FWD_GEN=2 asks for igemm_fwd2 (same tile shapes, same bits)
-// (pp: 0 = igemm_fwd2, 1 = igemm_pp, 2 = igemm_pp32)
+// (pp: 0 = igemm_fwd2, 1 = igemm_pp)
 static hipError_t launch_persistent(int pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
-    if (pp == 2 && igemm_pp32_supports(cfg, p)) return igemm_pp32_launch(cfg, p, gx, st);
     if (pp && igemm_pp_supports(cfg, p)) return igemm_pp_launch(cfg, p, gx, st);
     return igemm_fwd2_launch(cfg, ntap, p, gx, gy, st);
 }
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
-                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, hipStream_t st,
-                   void* bits_out = nullptr, const void* bits_in = nullptr) {
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, int ncu_arg, hipStream_t st) {
     const int kh = ntap / kw;
+    const int ncu = launch_ncu(ncu_arg);
+    if (ncu < 0) return RSU_EINVAL;
     const long out_bytes = (long)N * oH * oW * outC * 2;
     const int gen = env_int("RSU_FWD_GEN", 3);
     // the kernels address every tensor through 32-bit byte offsets of a buffer descriptor: a tensor must stay below 2 GiB (split
     // the batch otherwise -- L = 6, P = 388 reaches that at 29 patches per call)
-    if (out_bytes >= 0x7ffffff0L) return RSU_EINVAL;
+    if (out_bytes >= 0x7ffffff0L) return RSU_E2BIG;
     // RSU_FWD_GEN: 2 = igemm_fwd2 only; 3 (default) = the ping-pong kernel where it measured (or, untuned, is expected to be) faster;
     // 4 = the ping-pong kernel wherever it is built (tests)
     const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1 && dil == 1;
     for (int i = 0; i < nsrc; ++i)
-        if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) return RSU_EINVAL;
+        if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) return RSU_E2BIG;
     Fwd2Plan pl2;
     int ktot = 0;
     for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * ntap;
     const int env_cfg = env_int("RSU_FWD2_CFG", -1);
     const bool shared_chip = pad > 0 && env_int("RSU_PLAN_SHARED", 0) != 0;
     // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
-    const bool tunable = env_cfg < 0 && !accumulate && g_autotune.load() && env_int("RSU_AUTOTUNE", 1) != 0;
-    // 1-bit ReLU masks (rsu_conv2d_fwd_bits / rsu_conv2d_bwd_data_bits): [N][oH][oW][outC/8] bytes, addressed at (bf16 byte offset) / 16
-    const long bits_bytes = (long)N * oH * oW * (outC / 8);
-    if ((bits_out || bits_in) && (ntap != 9 || ostride != 1 || outC != Cout || accumulate || (bits_in && mask_src) || (bits_out && !relu) ||
-                                  bits_bytes >= (1L << 27)))
-        return RSU_EINVAL;
+    const int tune_mode = env_int("RSU_AUTOTUNE", 1) != 0 ? g_autotune.load() : RSU_TUNE_OFF;
+    const bool tunable = env_cfg < 0 && !accumulate && tune_mode != RSU_TUNE_OFF;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
-                                (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (bits_out ? 8 : 0) | (bits_in ? 16 : 0),
-                                ostride, g_cu_budget.load() * 8 + gen};
+                                (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0), ostride, ncu * 8 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
     bool tune_now = false;
     if (tunable) {
@@ -399,32 +412,19 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             tuned_cfg = it->second & 255;
             tuned_pp = it->second >> 8;
         } else {
-            tune_now = true;
+            tune_now = tune_mode == RSU_TUNE_MEASURE;
         }
     }
-    if (!plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip)) {
-        // a shape forced through RSU_FWD2_CFG whose halo tile does not fit this geometry: plan freely instead
-        if (!(env_cfg >= 0 && plan_fwd2(pl2, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip))) return RSU_EINVAL;
-    }
-    // RSU_FWD_GEN=5: igemm_pp32 wherever one of its shapes fits the launch -- a STATIC rule (its results differ from the other
-    // generations' in the last bits, so the choice between them must not hang on a timing); the tuner then picks among its shapes only
-    bool pp32 = false;
-    if (gen >= 5 && pp_ok && !bits_out && !bits_in) {
-        const int tn = igemm_fwd2_cfg_info(pl2.cfg).TN;
-        const int order[4] = {IGF2_CFG_128x256, IGF2_CFG_64x512, IGF2_CFG_128x128, IGF2_CFG_64x256};
-        for (int pass = 0; pass < 2 && !pp32; ++pass)
-            for (int k = 0; k < 4 && !pp32; ++k) {
-                const int cfg = pass == 0 ? (k == 0 ? pl2.cfg : -1) : order[k];
-                if (cfg < 0 || !igemm_pp32_has(cfg) || (pass == 1 && igemm_fwd2_cfg_info(cfg).TN != tn)) continue;
-                Fwd2Plan pc;
-                if (!plan_fwd2(pc, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
-                IgFwdParams pt;
-                memset(&pt, 0, sizeof(pt));
-                pt.stride = stride; pt.ostride = ostride; pt.dil = dil; pt.lsw = pc.lsw; pt.g = pc.g;
-                if (!igemm_pp32_supports(cfg, pt)) continue;
-                pl2 = pc;
-                pp32 = true;
-            }
+    if (!plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip)) {
+        // a shape forced through RSU_FWD2_CFG, or a tuned shape (an imported table), whose halo tile does not fit this geometry: plan
+        // freely instead (and forget the table entry)
+        if (tuned_cfg >= 0) {
+            std::lock_guard<std::mutex> lk(g_tune_mutex);
+            g_tuned.erase(tkey);
+            tuned_pp = -1;
+        }
+        if (!((env_cfg >= 0 || tuned_cfg >= 0) && plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip)))
+            return RSU_EINVAL;
     }
     IgFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -447,9 +447,6 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.bias = bias;
     p.out = (bf16_t*)out;
     p.mask_src = (const bf16_t*)mask_src;
-    p.bits_out = (unsigned char*)bits_out;
-    p.bits_in = (const unsigned char*)bits_in;
-    p.bits_bytes = (unsigned)bits_bytes;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
@@ -460,15 +457,17 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     {
         // kernel generation: the ping-pong kernel wherever it is instantiated (measured 10-20 % faster than igemm_fwd2 at every
         // shape; launch_persistent falls back to igemm_fwd2 for the rest) unless the tuner measured otherwise for this geometry
-        const int pp = pp32 ? 2 : ((pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0)) ? 1 : 0);
+        const int pp = (pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0)) ? 1 : 0;
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
+#ifdef RSU_DEV_KERNELS   // developer build only: timing ablations and the time-stamping kernels (the default build ignores these variables)
         p.dbg = env_int("RSU_FWD_DBG", 0);
         if (p.dbg & 128) {
             const char* sp = getenv("RSU_STAMP_PTR");
             p.stamps = sp ? (unsigned*)strtoull(sp, nullptr, 0) : nullptr;
         }
+#endif
         if (env_int("RSU_PLAN_DEBUG", 0)) {
             const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(pl2.cfg);
             const long tiles = (long)N * pl2.g.nstrips * pl2.g.tiles_per_strip;
@@ -500,14 +499,12 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
                 if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
                 Fwd2Plan pc;
-                if (!plan_fwd2(pc, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
+                if (!plan_fwd2(pc, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
                 IgFwdParams pt = p;
                 pt.ncob = pc.ncob;
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
-                for (int vpp = 0; vpp < 3; ++vpp) {  // the kernel generations of the shape
-                    if (pp32 != (vpp == 2)) continue;   // igemm_pp32 launches tune among igemm_pp32 shapes only, the others never try it
-                    if (vpp == 2 && !igemm_pp32_supports(cfg, pt)) continue;
+                for (int vpp = 0; vpp < 2; ++vpp) {  // the kernel generations of the shape
                     if (vpp == 1 && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
                     if (!vpp && gen >= 4 && pp_ok && igemm_pp_supports(cfg, pt)) continue;
                     float ms_min = 1e30f;
@@ -543,41 +540,12 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
 }
 
 extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
-                              int Win, int Cout, int dil, int relu, rsu_stream_t stream) {
+                              int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream) {
     if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || Cout % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
     const int Ho = Hin - 2 * dil, Wo = Win - 2 * dil;
     if (Ho < 1 || Wo < 2) return RSU_EINVAL;
     return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
-                   Ho, Wo, 1, 1, relu, 0, (hipStream_t)stream);
-}
-
-extern "C" size_t rsu_relu_bits_bytes(int N, int H, int W, int C) { return (size_t)N * H * W * (C / 8); }
-extern "C" int rsu_conv2d_fwd_bits(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* relu_bits, int N,
-                                   int Hin, int Win, int Cout, int dil, rsu_stream_t stream) {
-    if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !relu_bits || Cout % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
-    const int Ho = Hin - 2 * dil, Wo = Win - 2 * dil;
-    if (Ho < 1 || Wo < 2) return RSU_EINVAL;
-    return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
-                   Ho, Wo, 1, 1, 1, 0, (hipStream_t)stream, relu_bits, nullptr);
-}
-extern "C" int rsu_conv_first_fwd_bits(const void* in16, const void* packed, const float* b, void* y, void* relu_bits, int N, int H, int W,
-                                       int Cout, int dil, rsu_stream_t stream) {
-    if (!in16 || !packed || !y || !relu_bits || Cout % 8 || H <= 2 * dil || W <= 2 * dil + 1 || (dil != 1 && dil != 2)) return RSU_EINVAL;
-    rsu_src_t s;
-    s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
-    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
-    return run_fwd(&s, 1, packed, 0, rup(Cout, 128) / 16, 0, b, y, nullptr, N, H, W, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0, Ho, Wo, 1, 1, 1, 0,
-                   (hipStream_t)stream, relu_bits, nullptr);
-}
-extern "C" int rsu_conv2d_bwd_data_bits(const void* dz, const void* packed_bwd, void* dx, const void* relu_bits, int N, int H, int W,
-                                        int Cin_total, int Cout, int dil, rsu_stream_t stream) {
-    if (!dz || !packed_bwd || !dx || !relu_bits || Cout % 8 || Cin_total % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
-    const int Hd = H - 2 * dil, Wd = W - 2 * dil;  // dz size
-    if (Hd < 1 || Wd < 1 || W < 2) return RSU_EINVAL;
-    rsu_src_t s;
-    s.ptr = dz; s.H = Hd; s.W = Wd; s.C = Cout; s.oy = 0; s.ox = 0;
-    return run_fwd(&s, 1, packed_bwd, 0, rup(Cin_total, 128) / 16, 0, nullptr, dx, nullptr, N, Hd, Wd, H, W, Cin_total, Cin_total, 9, 3, dil,
-                   1, 2 * dil, H, W, 1, 1, 0, 0, (hipStream_t)stream, nullptr, relu_bits);
+                   Ho, Wo, 1, 1, relu, 0, ncu, (hipStream_t)stream);
 }
 
 extern "C" size_t rsu_packed_first_bytes(int Cout) {
@@ -589,17 +557,17 @@ extern "C" int rsu_pack_conv_first(const float* w, void* packed, int Cout, rsu_s
     return do_pack(w, packed, 9, Cout, seg, 1, (long)3 * Cout, 1, Cout, 0, (hipStream_t)stream);
 }
 extern "C" int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout, int dil,
-                                  rsu_stream_t stream) {
+                                  int ncu, rsu_stream_t stream) {
     if (!in16 || !packed || !y || Cout % 8 || H <= 2 * dil || W <= 2 * dil + 1 || (dil != 1 && dil != 2)) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
     const int Ho = H - 2 * dil, Wo = W - 2 * dil;
     return run_fwd(&s, 1, packed, 0, rup(Cout, 128) / 16, 0, b, y, nullptr, N, H, W, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0, Ho, Wo, 1, 1, 1, 0,
-                   (hipStream_t)stream);
+                   ncu, (hipStream_t)stream);
 }
 
 extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
-                                   int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, rsu_stream_t stream) {
+                                   int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, rsu_stream_t stream) {
     if (!dz || !packed_bwd || !dx || Cout % 8 || ci_cnt % 8 || ci_off % 32 || ci_off + ci_cnt > Cin_total || (dil != 1 && dil != 2))
         return RSU_EINVAL;
     const int Hd = H - 2 * dil, Wd = W - 2 * dil;  // dz size
@@ -607,13 +575,15 @@ extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void*
     rsu_src_t s;
     s.ptr = dz; s.H = Hd; s.W = Wd; s.C = Cout; s.oy = 0; s.ox = 0;
     return run_fwd(&s, 1, packed_bwd, 0, rup(Cin_total, 128) / 16, ci_off / 16, nullptr, dx, relu_src, N, Hd, Wd, H, W, ci_cnt, ci_cnt, 9,
-                   3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, (hipStream_t)stream);
+                   3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, ncu, (hipStream_t)stream);
 }
 
 // igemm_ct launch (transposed conv forward / backward-data as a ping-pong GEMM): one workgroup per budgeted CU, column blocks fastest
 static unsigned magic_floor32(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned)d); }
 static int run_ct(int mode, const void* a, int Ca, int N, int H, int W, const void* wp, long phase_stride, int ntiles_w, const float* bias,
-                  void* out, int outC, int Cn, const void* mask_src, hipStream_t st) {
+                  void* out, int outC, int Cn, const void* mask_src, int ncu_arg, hipStream_t st) {
+    const int ncu = launch_ncu(ncu_arg);
+    if (ncu < 0) return RSU_EINVAL;
     IgCtParams p;
     memset(&p, 0, sizeof(p));
     p.a = (const bf16_t*)a;
@@ -633,7 +603,7 @@ static int run_ct(int mode, const void* a, int Ca, int N, int H, int W, const vo
     p.nnb = cdiv((mode == 0 ? 2 : 1) * Cn, 128);
     p.ncob = (mode == 0 ? 2 : 1) * p.nnb;
     const int ntile_m = cdiv(N * H * W, 256);
-    int cols = g_cu_budget.load() / p.ncob;   // workgroups per column block
+    int cols = ncu / p.ncob;   // workgroups per column block
     if (cols < 1) cols = 1;
     if (cols > ntile_m) cols = ntile_m;
     HIP_CHECK_RET(igemm_ct_launch(mode, p, cols * p.ncob, st));
@@ -641,7 +611,7 @@ static int run_ct(int mode, const void* a, int Ca, int N, int H, int W, const vo
 }
 
 extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
-                                rsu_stream_t stream) {
+                                int ncu, rsu_stream_t stream) {
     if (!x || !packed_fwd || !y || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = x; s.H = H; s.W = W; s.C = Cin; s.oy = 0; s.ox = 0;
@@ -649,19 +619,20 @@ extern "C" int rsu_convT2x2_fwd(const void* x, const void* packed_fwd, const flo
     const long per = (long)(rsu_packed_bytes(1, Cout, seg, 1) / 2);
     // RSU_CT_GEN=1: the 1-tap launches of igemm_fwd2 (one per output phase); default: the ping-pong GEMM of igemm_ct.hip
     if (env_int("RSU_CT_GEN", 2) >= 2 && igemm_ct_supports(0, N, H, W, Cin, Cout) && (long)N * 4 * H * W * Cout * 2 < 0x7ffffff0L)
-        return run_ct(0, x, Cin, N, H, W, packed_fwd, per, rup(Cout, 128) / 16, bias, y, Cout, Cout, nullptr, (hipStream_t)stream);
+        return run_ct(0, x, Cin, N, H, W, packed_fwd, per, rup(Cout, 128) / 16, bias, y, Cout, Cout, nullptr, ncu, (hipStream_t)stream);
     return run_fwd(&s, 1, packed_fwd, per, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, H, W, H, W, Cout, Cout, 1, 1, 1, 1, 0, 2 * H, 2 * W,
-                   2, 4, 0, 0, (hipStream_t)stream);
+                   2, 4, 0, 0, ncu, (hipStream_t)stream);
 }
 
 extern "C" int rsu_convT2x2_bwd_data(const void* dy, const void* packed_bwd, void* dx, const void* relu_src, float out_scale, int N, int H,
-                                     int W, int Cin, int Cout, rsu_stream_t stream) {
+                                     int W, int Cin, int Cout, int ncu, rsu_stream_t stream) {
     if (!dy || !packed_bwd || !dx || Cin % 8 || Cout % 8 || W < 2 || !(out_scale > 0.f)) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
     const bool ct = env_int("RSU_CT_GEN", 2) >= 2 && igemm_ct_supports(1, N, H, W, Cout, Cin) && (long)N * 4 * H * W * Cout * 2 < 0x7ffffff0L;
-    const int rc = ct ? run_ct(1, dy, Cout, N, H, W, packed_bwd, 0, rup(Cin, 128) / 16, nullptr, dx, Cin, Cin, relu_src, (hipStream_t)stream) : run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0,
-                           H, W, 1, 1, 0, 0, (hipStream_t)stream);
+    const int rc = ct ? run_ct(1, dy, Cout, N, H, W, packed_bwd, 0, rup(Cin, 128) / 16, nullptr, dx, Cin, Cin, relu_src, ncu, (hipStream_t)stream)
+                      : run_fwd(&s, 1, packed_bwd, 0, rup(Cin, 128) / 16, 0, nullptr, dx, relu_src, N, 2 * H, 2 * W, H, W, Cin, Cin, 4, 2, 1, 2, 0,
+                                H, W, 1, 1, 0, 0, ncu, (hipStream_t)stream);
     if (rc != RSU_OK || out_scale == 1.f) return rc;
     // 1/keep of a dropout in front of the transposed conv: a separate pass over the (small) gradient tensor, training with
     // dropout only -- the MFMA kernel's epilogue is left alone (see DESIGN.md section 4 on what scaling there cost)
@@ -688,7 +659,7 @@ static size_t wgrad_max_slabs(int cfg, int Cf, int Cs) {
     return (size_t)(a > b ? a : b);
 }
 struct WgPlan { int cfg; TileGeo g; int gx, gy, nsplit, ntiles, lsw, nbuf; };
-static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
+static bool plan_wgrad(WgPlan& pl, int ncu, int cfg, int N, int Hf, int Wf, int Cf, int Cs, int ntap, int kh, int kw, int dil, int stride) {
     pl.cfg = cfg;
     const int csb = igemm_wgrad_csb(cfg), cfbk = igemm_wgrad_cfb(cfg);
     const int tmk = igemm_wgrad_tmk(cfg);
@@ -710,21 +681,23 @@ static bool plan_wgrad(WgPlan& pl, int cfg, int N, int Hf, int Wf, int Cf, int C
     pl.gx = cdiv(Cf, cfbk);
     pl.gy = cdiv(Cs, csb);
     pl.ntiles = N * pl.g.nstrips * pl.g.tiles_per_strip;
-    const int want = wgrad_max_split(cfg, Cf, Cs, g_cu_budget.load());  // workgroups along z; each writes one slab (workspace sized for 256)
+    const int want = wgrad_max_split(cfg, Cf, Cs, ncu);  // workgroups along z; each writes one slab (workspace sized for 256)
     pl.nsplit = want < pl.ntiles ? want : pl.ntiles;
     (void)ntap;
     return true;
 }
 
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
-                     int cs_off, int N, int ntap, int kw, int dil, int stride, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu_arg, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
+    const int ncu = launch_ncu(ncu_arg);
+    if (ncu < 0) return RSU_EINVAL;
     // 32-bit byte offsets inside the kernel: both operand tensors must stay below 2 GiB (beyond that the offsets wrapped
     // silently and only the weight gradients came out wrong)
-    if ((long)N * Hf * Wf * Cf * 2 >= 0x7ffffff0L || (long)N * S->H * S->W * S->C * 2 >= 0x7ffffff0L) return RSU_EINVAL;
+    if ((long)N * Hf * Wf * Cf * 2 >= 0x7ffffff0L || (long)N * S->H * S->W * S->C * 2 >= 0x7ffffff0L) return RSU_E2BIG;
     WgPlan pl;
     const int wide = wgrad_pick_cfg(cfg, Cf);
-    if (wide != cfg && plan_wgrad(pl, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
-    else if (!plan_wgrad(pl, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
+    if (wide != cfg && plan_wgrad(pl, ncu, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
+    else if (!plan_wgrad(pl, ncu, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
     IgWgradParams p;
     memset(&p, 0, sizeof(p));
     p.F = (const bf16_t*)F;
@@ -752,7 +725,9 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.lsw = pl.lsw;
     p.nbuf = pl.nbuf;
     p.nsw = igemm_wgrad_nsw(cfg, pl.g.npix_max);
+#ifdef RSU_DEV_KERNELS
     p.dbg = env_int("RSU_WG_DBG", 0);
+#endif
     p.g = pl.g;
     // RSU_WG_GEN=1: igemm_wgrad everywhere; default: the ping-pong kernel where it is built (same slabs, same bits)
     if (env_int("RSU_WG_GEN", 2) >= 2 && igemm_wgpp_supports(cfg, ntap, p))
@@ -771,37 +746,37 @@ extern "C" size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int 
     return wgrad_max_slabs(IGW_CFG_64x64, Cout, src_C) * (9 * (size_t)Cin_total * Cout + Cout);
 }
 extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
-                                     int Cin_total, int ci_off, int Cout, int dil, rsu_stream_t stream) {
+                                     int Cin_total, int ci_off, int Cout, int dil, int ncu, rsu_stream_t stream) {
     if (!src || !src->ptr || !dz || !dw || !ws || src->C % 8 || Cout % 8 || ci_off + src->C > Cin_total || (dil != 1 && dil != 2))
         return RSU_EINVAL;
     if (src->oy < 0 || src->ox < 0 || src->oy + Ho + 2 * dil > src->H || src->ox + Wo + 2 * dil > src->W || Wo < 2) return RSU_EINVAL;
     // F = dz (cf = co), S = layer input (cs = ci): slab[tap][ci][co] = HWIO
-    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, (hipStream_t)stream, db);
+    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db);
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
     return wgrad_max_slabs(IGW_CFG_64x64, Cin, Cout) * (4 * (size_t)Cout * Cin + Cout);
 }
 extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W, int Cin,
-                                       int Cout, rsu_stream_t stream) {
+                                       int Cout, int ncu, rsu_stream_t stream) {
     if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
     // F = x (cf = ci), S = dy (cs = co), stride 2: slab[tap(a,b)][co][ci] = K layout
-    return run_wgrad(IGW_CFG_64x64, x, H, W, Cin, &s, dK, ws, Cout, Cin, 0, N, 4, 2, 1, 2, (hipStream_t)stream, nullptr, db);
+    return run_wgrad(IGW_CFG_64x64, x, H, W, Cin, &s, dK, ws, Cout, Cin, 0, N, 4, 2, 1, 2, ncu, (hipStream_t)stream, nullptr, db);
 }
 
 extern "C" size_t rsu_conv_first_bwd_ws_floats(int Cout) {
     return (wgrad_max_slabs(IGW_CFG_64x16, Cout, 16) + 1) * (9 * 16 * (size_t)Cout + Cout);
 }
 extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float* dw1, float* gxc, float* db, float* ws, int N, int H, int W,
-                                         int Cout, int dil, rsu_stream_t stream) {
+                                         int Cout, int dil, int ncu, rsu_stream_t stream) {
     if (!in16 || !dz || !dw1 || !ws || Cout % 8 || (dil != 1 && dil != 2) || W - 2 * dil < 2) return RSU_EINVAL;
     rsu_src_t s;
     s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
     float* tmp = ws;                          // [9][16][Cout]
     float* slabs = ws + (size_t)9 * 16 * Cout;
-    int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, (hipStream_t)stream, db);
+    int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db);
     if (rc) return rc;
     HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));
     return RSU_OK;

@@ -40,24 +40,6 @@ __device__ __forceinline__ unsigned pos_mask_pk_bf16(unsigned m, unsigned /*ones
     return t;
 }
 
-// ---- 1-bit ReLU masks. A lane's 16-byte store holds 8 consecutive channels of one pixel as 4 packed dwords (dword i = channels 2i
-// in the low, 2i+1 in the high half): their "> 0" flags are ONE byte of the mask tensor [pixel][C/8] (bit k = channel 8*byte + k),
-// at byte offset (bf16 byte offset) / 16. relu_bits_pk: the byte of a post-ReLU result (values >= 0: > 0 <=> != 0).
-__device__ __forceinline__ unsigned relu_bits_pk(const u32x4& r, unsigned ones_pk /* 0x00010001 in a VGPR */) {
-    unsigned t0, t1, t2, t3;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(r[0]), "v"(ones_pk));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(r[1]), "v"(ones_pk));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t2) : "v"(r[2]), "v"(ones_pk));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t3) : "v"(r[3]), "v"(ones_pk));
-    const unsigned a = t0 | (t1 << 2) | (t2 << 4) | (t3 << 6);  // low-half flags at bits 0,2,4,6, high-half flags at 16,18,20,22
-    return (a | (a >> 15)) & 0xffu;
-}
-// ... and back: bits 2i, 2i+1 of the byte as a packed 0 / 0xffff mask for dword i
-__device__ __forceinline__ unsigned relu_mask_from_bits(unsigned b, int i) {
-    const unsigned z = __builtin_amdgcn_ubfe(b, 2 * i, 1) | (__builtin_amdgcn_ubfe(b, 2 * i + 1, 1) << 16);
-    return __umul24(z, 0xffffu);
-}
-
 // ---- in-place MFMA accumulate: acc += A x B with vDst == SrcC guaranteed (inline asm, tied operand): no register is freed by
 // an MFMA, so the compiler cannot rename an accumulator and re-use its old registers while the matrix pipe still reads them.
 // The asm is opaque to hipcc's hazard recogniser, so the CALLER owns the wait states around it (DESIGN.md section 4;
@@ -66,10 +48,6 @@ __device__ __forceinline__ unsigned relu_mask_from_bits(unsigned b, int i) {
 // operand written by a VALU instruction followed by `s_nop 3` before the MFMA that reads it.
 __device__ __forceinline__ void mfma_bf16_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-// the 32x32x16 form (igemm_pp32.hip): 16 accumulator registers per lane, 8 passes
-__device__ __forceinline__ void mfma32_bf16_inplace(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // XCD-aware workgroup numbering for one-workgroup-per-CU launches: the dispatcher deals consecutive workgroup ids round-robin over the 8
 // XCDs (id & 7), each with its own L2. This turns the hardware id into a logical id such that each XCD owns a CONTIGUOUS range of logical

@@ -150,7 +150,11 @@ class ConvolutionalModel:
                     self._bucketer.reset()
                     net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
                     self._bucketer.finish()
-                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=lambda n: setattr(self.net, "backward_cu_budget", n))
+                def set_budget(n):   # every candidate budget gets its own (untimed) tile-shape tuning pass before it is timed
+                    net.backward_cu_budget = n
+                    net.ensure_tuned()
+                self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=set_budget)
+        net.ensure_tuned()   # the explicit tile-shape tuning pass (untimed, weights untouched): once, in front of the first step
         # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
         # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
         net.forward_device(keep=float(opts.dropout))
@@ -287,6 +291,7 @@ class ConvolutionalModel:
         else:
             per = -(-num_patches // self.world)
             lo, hi = min(self.rank * per, num_patches), min((self.rank + 1) * per, num_patches)
+            net.ensure_tuned(training=False)
             for t0 in range(lo, hi, B):
                 nb = min(B, hi - t0)
                 if nb < B:
@@ -343,6 +348,7 @@ class ConvolutionalModel:
             k = max(len(rx), len(ry))
             Pk = P + (k - 1) * g
             wn = self._window_net(Pk, Bw)
+            wn.ensure_tuned(training=False)   # the window nets have geometries of their own: one untimed tuning pass each
             Sk = wn.S
             ox0, oy0 = rx[0] * stride, ry[0] * stride
             h, w = min(Sk, Hp - oy0), min(Sk, Hp - ox0)

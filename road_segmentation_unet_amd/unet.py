@@ -109,18 +109,19 @@ class UNet:
         self.wstream = None    # side stream for the weight-gradient launches (see _Side); wstreams: all of them
         self.wstreams = []
         self._split = None     # (full, main, [side ...]) CU budgets while a backward pass shares the chip between the streams
-        self.backward_cu_budget = None   # CUs the backward launches may plan for in total (None: the library's budget)
-        self._budget_before = 256
+        self.backward_cu_budget = None   # CUs the backward launches may plan for in total (None: the library's default)
+        self._ncu = 0          # `ncu` argument of the MFMA launches issued now (0: the library's default budget)
+        self._tuned = set()    # (training?, backward_cu_budget) combinations the tuning pass has run for (tune / ensure_tuned)
         self._side_rr = 0
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
             self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
             self.wstream = self.wstreams[0]
-        self.bits, self._bits_of = {}, {}
         self.pool_code = {}
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
+        self._check_tensor_sizes()
         self._alloc_params(params if params is not None else glorot_uniform_params(num_layers, root_size, dilated_layers, seed))
         self._alloc_buffers()
         self.repack()
@@ -168,6 +169,17 @@ class UNet:
                 self.acc[n].copy_(torch.from_numpy(np.ascontiguousarray(d[n + "/Momentum"], dtype=np.float32)))
         self.global_step = int(d.get("global_step", 0))
         self.repack()
+
+    def _check_tensor_sizes(self):
+        """The kernels address a tensor through 32-bit byte offsets: every activation must stay below 2 GiB (the entry points
+        return RSU_E2BIG otherwise). Checked here, where the batch is chosen, with the largest batch that fits."""
+        h0 = self.S - 2                                    # level-0 conv1 output, `root` channels: the largest tensor of a level
+        per_patch = max(self.S * self.S * 16, h0 * h0 * self.root) * 2
+        limit = 0x7ffffff0
+        if self.B * per_patch >= limit:
+            raise _lib.RsuError("batch_size %d is too large for num_layers=%d patch_size=%d: the level-0 activations (%d bytes per patch) "
+                                "must stay below 2 GiB per tensor; the largest per-GPU batch is %d"
+                                % (self.B, self.L, self.P, per_patch, (limit - 1) // per_patch))
 
     # ------------------------------------------------------------------ buffers
     def _bf(self, *shape):
@@ -231,16 +243,6 @@ class UNet:
             self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
             # (one workspace per stream that launches weight gradients: their slabs are live at the same time)
             self.ws_side = [self.ws] + [torch.zeros_like(self.ws) for _ in self.wstreams[1:]]
-            # 1-bit ReLU masks of the conv1 / atrous_conv1 outputs (the ReluGrad masks of the conv2 backward-data launches): written by
-            # the forward conv beside its activation, read instead of it in backward (16x fewer bytes). Built and tested, but OFF by default (RSU_RELU_BITS=1 turns it on): measured -0.8 % on the step -- what the bf16 mask costs backward-data is one exposed round trip per tile, not its bytes, and the forward epilogue pays for building the bits.
-            self.bits = {}
-            if os.environ.get("RSU_RELU_BITS", "0") == "1":
-                for k, t in self.act.items():
-                    if k.startswith("c1_") or k.startswith("d1_"):
-                        nb = lib.rsu_relu_bits_bytes(t.shape[0], t.shape[1], t.shape[2], t.shape[3])
-                        if nb < (1 << 27):
-                            self.bits[k] = torch.zeros(nb, dtype=torch.uint8, device=dev)
-            self._bits_of = {self.act[k].data_ptr(): b for k, b in self.bits.items()}
             self.gfirst = torch.zeros((2, 9, 12, self.root), dtype=torch.float32, device=dev)  # gx of conv1 / atrous_conv1 (rsu.h)
             # code bytes of the max-pools (argmax + ReLU bits per pooled element, rsu_maxpool2x2_fwd_code): the gradient junction of a
             # level reads them instead of the level's conv2 activation. RSU_POOL_CODE=0: it reads the activation (same bits)
@@ -337,11 +339,11 @@ class UNet:
     # WORKGROUP (a 295-KB slab each, written and read back by the reduce kernel): half the workgroups, half that traffic --
     # and persistent kernels on fewer CUs lose less to their last, partly filled round of tiles. "0" = both plan for every CU.
     def _begin_split(self):
-        """CU budgets of the backward pass: `backward_cu_budget` (set by the data-parallel host: CUs left to RCCL's channel workgroups
-        while the gradient exchange overlaps the backward pass; the forward pass keeps the whole chip) shared out between the streams"""
+        """CU shares of the backward pass: `backward_cu_budget` (set by the data-parallel host: CUs left to RCCL's channel workgroups
+        while the gradient exchange overlaps the backward pass; the forward pass keeps the whole chip) shared out between the
+        streams. Every launch carries its share as its own `ncu` argument (self._ncu): no library state changes between launches."""
         self._split = None
-        self._budget_before = _lib.lib().rsu_get_cu_budget()
-        full = self.backward_cu_budget or self._budget_before
+        full = self.backward_cu_budget or _lib.lib().rsu_get_cu_budget()
         spec = os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT)
         parts = None
         if self.wstreams and spec not in ("0", ""):
@@ -352,34 +354,35 @@ class UNet:
             if parts is not None and (len(parts) != len(self.wstreams) + 1 or min(parts) < 1):
                 parts = None
         if parts is None:
-            if full != self._budget_before:
-                call("rsu_set_cu_budget", full)
+            self._ncu = full if self.backward_cu_budget else 0
             return
         parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
         self._split = (full, parts[0], parts[1:])
-        call("rsu_set_cu_budget", parts[0])
+        self._ncu = parts[0]
 
     def _end_split(self):
         self._split = None
-        if _lib.lib().rsu_get_cu_budget() != self._budget_before:
-            call("rsu_set_cu_budget", self._budget_before)
+        self._ncu = 0
 
     class _Side:
-        """`with UNet._Side(net) as side:` -- launches inside go to the next side stream (round robin); side.ws is its workspace"""
+        """`with UNet._Side(net) as side:` -- launches inside go to the next side stream (round robin) and plan for that stream's share
+        of the chip; side.ws is its workspace"""
 
         def __init__(self, net, alone=False):
             self.net, self.ctx, self.alone = net, None, alone  # alone: nothing is left to run beside it on the main stream
             self.ws = net.ws if net.training else None
+            self.saved_ncu = net._ncu
 
         def __enter__(self):
             n = self.net
+            self.saved_ncu = n._ncu
             if not n.wstreams:
                 return self
             k = n._side_rr % len(n.wstreams)
             n._side_rr += 1
             self.ws = n.ws_side[k]
             if n._split is not None:
-                call("rsu_set_cu_budget", n._split[0] if self.alone else n._split[2][k])
+                n._ncu = n._split[0] if self.alone else n._split[2][k]
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(n.device))
             n.wstreams[k].wait_event(ev)
@@ -388,10 +391,11 @@ class UNet:
             return self
 
         def __exit__(self, *a):
-            if self.ctx is not None:
-                self.ctx.__exit__(*a)
-                if self.net._split is not None:
-                    call("rsu_set_cu_budget", self.net._split[1])
+            try:
+                if self.ctx is not None:
+                    self.ctx.__exit__(*a)
+            finally:
+                self.net._ncu = self.saved_ncu   # on error paths too
 
     def _join_side(self):
         for s in self.wstreams:
@@ -402,24 +406,13 @@ class UNet:
         cout = out.shape[3]
         cin = sum(s.C for s in srcs)
         ho = hin - 2 * dil
-        bits = self._bits_of.get(out.data_ptr()) if self.training else None
-        if bits is not None:  # the activation doubles as a ReluGrad mask in backward: emit its 1-bit form as well
-            self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd_bits", arr, len(srcs),
-                        _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), _ptr(bits), self.B, hin, hin, cout, dil,
-                        self._stream())
-            return
         self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd", arr, len(srcs),
                     _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
-                    self._stream())
+                    self._ncu, self._stream())
 
     def _conv_first(self, name, out, h, dil, st):
-        bits = self._bits_of.get(out.data_ptr()) if self.training else None
-        if bits is not None:
-            call("rsu_conv_first_fwd_bits", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
-                 _ptr(bits), self.B, h, h, self.root, dil, st)
-        else:
-            call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
-                 self.B, h, h, self.root, dil, st)
+        call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
+             self.B, h, h, self.root, dil, self._ncu, st)
 
     def dropout_key(self, site):
         """32-bit key of dropout site `site` (encoder level i -> i, decoder stage i -> L + i: the 2L-1 tf.nn.dropout calls of
@@ -469,7 +462,7 @@ class UNet:
                 call("rsu_dropout_fwd", _ptr(net), _ptr(drop), net.numel(), keep, self.dropout_key(L + i), st)
                 net = drop
             call("rsu_convT2x2_fwd", _ptr(net), _ptr(self.pk["up_conv_%d/kernel" % i, "fwd"]), _ptr(self.w["up_conv_%d/bias" % i]), _ptr(up),
-                 B, h, h, net.shape[3], up.shape[3], st)
+                 B, h, h, net.shape[3], up.shape[3], self._ncu, st)
             h = 2 * h
             srcs = [_src(a["c2_%d" % lvl], h, h)]
             if self.dilated:
@@ -495,7 +488,8 @@ class UNet:
                 s = _src(t, win, win)
                 db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
                 self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
-                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil, st)
+                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil,
+                            self._ncu, st)
                 off += t.shape[3]
 
     def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
@@ -503,14 +497,9 @@ class UNet:
         cout = self.w[name + "/kernel"].shape[3]
         cnt = dx.shape[3]
         ho = hin - 2 * dil
-        bits = self._bits_of.get(relu_src.data_ptr()) if relu_src is not None else None
-        if bits is not None and not accumulate and src_index == 0 and cnt == self.w[name + "/kernel"].shape[2]:
-            self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data_bits", _ptr(dz),
-                        _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(bits), self.B, hin, hin, cnt, cout, dil, self._stream())
-            return
         self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data", _ptr(dz),
                     _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
-                    cout, dil, self._stream())
+                    cout, dil, self._ncu, self._stream())
 
     def backward_device(self, inv_count):
         """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count)."""
@@ -518,6 +507,23 @@ class UNet:
         keep = self.keep
         last = a[self.last_name]
         self._begin_split()
+        try:
+            self._backward_body(inv_count)
+        finally:
+            self._end_split()   # (an exception inside must not leave later launches planned for a share of the chip)
+        # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
+        #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
+        inv_keep = float(np.float32(1.0) / np.float32(keep))
+        gk, gb = self.g["color_space_adjust/kernel"], self.g["color_space_adjust/bias"]
+        call("rsu_color_adjust_bwd", _ptr(self.gfirst[0]), _ptr(self.w["conv_0/conv1/kernel"]), _ptr(gk), _ptr(gb), self.root, inv_keep, 0, st)
+        if self.dilated and L > 1:
+            call("rsu_color_adjust_bwd", _ptr(self.gfirst[1]), _ptr(self.w["conv_dilut_0/atrous_conv1/kernel"]), _ptr(gk), _ptr(gb), self.root,
+                 inv_keep, 1, st)
+
+    def _backward_body(self, inv_count):
+        B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
+        keep = self.keep
+        last = a[self.last_name]
         self.loss_sum.zero_()
         call("rsu_head_fwd_bwd", _ptr(last), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.labels),
              _ptr(self.prob), _ptr(self.loss_sum), _ptr(g[self.last_name]), _ptr(self.g["weight_output/kernel"]),
@@ -546,9 +552,9 @@ class UNet:
             hh = h // 2
             with UNet._Side(self) as side:
                 call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
-                     _ptr(side.ws), B, hh, hh, upin.shape[3], nf, self._stream())
+                     _ptr(side.ws), B, hh, hh, upin.shape[3], nf, self._ncu, self._stream())
             call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), float(np.float32(1.0) / np.float32(keep)), B, hh, hh,
-                 upin.shape[3], nf, st)
+                 upin.shape[3], nf, self._ncu, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
         # ---- encoder, level L-1 .. 0
         for i in reversed(range(L)):
@@ -570,7 +576,7 @@ class UNet:
             else:
                 with UNet._Side(self, alone=not (self.dilated and L > 1)) as side:
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
-                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._stream())
+                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._ncu, self._stream())
             if self.dilated and i < L - 1:
                 d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
@@ -586,22 +592,50 @@ class UNet:
                 else:
                     with UNet._Side(self, alone=True) as side:
                         call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dzd1), _ptr(self.g["conv_dilut_0/atrous_conv1/kernel"]),
-                             _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(side.ws), B, h, h, nf, 2, self._stream())
+                             _ptr(self.gfirst[1]), _ptr(self.g["conv_dilut_0/atrous_conv1/bias"]), _ptr(side.ws), B, h, h, nf, 2, self._ncu,
+                             self._stream())
             if i > 0:
                 # first LIVE variable of the level in creation order: the dilated pair of level L-1 is dead and sits behind n_live
                 # (marking it ready launched nothing, and the largest block waited for level L-2)
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if (self.dilated and i < L - 1) else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
         self._join_side()
-        self._end_split()
-        # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
-        #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
-        inv_keep = float(np.float32(1.0) / np.float32(keep))
-        gk, gb = self.g["color_space_adjust/kernel"], self.g["color_space_adjust/bias"]
-        call("rsu_color_adjust_bwd", _ptr(self.gfirst[0]), _ptr(self.w["conv_0/conv1/kernel"]), _ptr(gk), _ptr(gb), self.root, inv_keep, 0, st)
-        if self.dilated and L > 1:
-            call("rsu_color_adjust_bwd", _ptr(self.gfirst[1]), _ptr(self.w["conv_dilut_0/atrous_conv1/kernel"]), _ptr(gk), _ptr(gb), self.root,
-                 inv_keep, 1, st)
+
+    def tune(self, training=None):
+        """The explicit tile-shape tuning pass (rsu.h rsu_set_autotune): ONE untimed forward (+ backward) over random data with the
+        library in RSU_TUNE_MEASURE mode -- every conv geometry of this network at the CU shares its launches use is timed once on an
+        idle device -- then back to RSU_TUNE_LOOKUP, in which the launch entry points never measure nor synchronise. Weights, Momentum
+        slots and the step counter are untouched; x / labels are restored. All shapes give the same bits: this only moves time. Under
+        data parallelism call it before the first collective is in flight (and again after changing backward_cu_budget)."""
+        lib = _lib.lib()
+        training = self.training if training is None else (training and self.training)
+        self._tuned.add((bool(training), self.backward_cu_budget))
+        if lib.rsu_get_autotune() == _lib.TUNE_OFF or os.environ.get("RSU_AUTOTUNE", "1") == "0":
+            return
+        x0, l0 = self.x.clone(), self.labels.clone()
+        g = torch.Generator(device="cpu").manual_seed(12345)
+        self.x.copy_(torch.rand(tuple(self.x.shape), generator=g))
+        self.labels.copy_((torch.rand(tuple(self.labels.shape), generator=g) < 0.2).to(torch.int64))
+        on_grads, self.on_grads = self.on_grads, None   # no gradient exchange from inside the tuning pass
+        prof, self.prof = self.prof, None
+        call("rsu_set_autotune", _lib.TUNE_MEASURE)
+        try:
+            self.forward_device()
+            if training:
+                self.backward_device(1.0 / (self.B * self.P * self.P))
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+        finally:
+            call("rsu_set_autotune", _lib.TUNE_LOOKUP)
+            self.on_grads, self.prof = on_grads, prof
+            self.x.copy_(x0)
+            self.labels.copy_(l0)
+
+    def ensure_tuned(self, training=None):
+        """tune() once per (forward-only / training, backward CU budget): what the hosts call in front of their first step"""
+        training = self.training if training is None else (training and self.training)
+        if (bool(training), self.backward_cu_budget) not in self._tuned and ((True, self.backward_cu_budget) not in self._tuned):
+            self.tune(training)
 
     # ------------------------------------------------------------------ optimizer
     def learning_rate(self, lr0):

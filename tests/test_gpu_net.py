@@ -172,7 +172,7 @@ def test_linearity_property_full_size_layer():
         assert bool((xd.float().cpu() == torch.from_numpy(x)).all())  # exactly representable
         y = torch.zeros((N, H - 2, H - 2, C), dtype=torch.bfloat16, device=hu.DEV)
         s = (RsuSrc * 1)(hu.src_of(xd, H, H))
-        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), None, hu.ptr(y), N, H, H, C, 1, 0, hu.stream())
+        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), None, hu.ptr(y), N, H, H, C, 1, 0, 0, hu.stream())
         keep.append(xd)
         outs.append(y.float())
     torch.cuda.synchronize()

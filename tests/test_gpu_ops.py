@@ -47,7 +47,7 @@ def test_conv2d_fwd(N, H, W, Cin, Cout, dil, relu):
     Ho, Wo = H - 2 * dil, W - 2 * dil
     y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
     s = (RsuSrc * 1)(hu.src_of(xd, H, W))
-    call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, dil, relu, hu.stream())
+    call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, dil, relu, 0, hu.stream())
     ref = U.conv2d_fwd(x, hu.q(w), b, dil=dil, relu=bool(relu))
     hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd")
 
@@ -66,7 +66,7 @@ def test_conv2d_fwd_three_cropped_sources():
     y = torch.zeros((N, h - 2, w - 2, 64), dtype=torch.bfloat16, device=hu.DEV)
     srcs = (RsuSrc * 3)(hu.src_of(ad, h, w), hu.src_of(bd_, h, w), hu.src_of(cd, h, w))
     biasd = hu.dev_f32(bias)
-    call("rsu_conv2d_fwd", srcs, 3, hu.ptr(wp), hu.ptr(biasd), hu.ptr(y), N, h, w, 64, 1, 1, hu.stream())
+    call("rsu_conv2d_fwd", srcs, 3, hu.ptr(wp), hu.ptr(biasd), hu.ptr(y), N, h, w, 64, 1, 1, 0, hu.stream())
     cat = np.concatenate([U.center_crop(a, h, w), U.center_crop(bsrc, h, w), c], axis=3)
     ref = U.conv2d_fwd(cat, hu.q(W), bias, relu=True)
     hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd 3 sources")
@@ -82,7 +82,7 @@ def test_conv2d_fwd_odd_channel_segments():
     y = torch.zeros((N, h - 2, h - 2, 16), dtype=torch.bfloat16, device=hu.DEV)
     ad, cd = hu.dev_bf16(a), hu.dev_bf16(c)
     srcs = (RsuSrc * 2)(hu.src_of(ad, h, h), hu.src_of(cd, h, h))
-    call("rsu_conv2d_fwd", srcs, 2, hu.ptr(wp), None, hu.ptr(y), N, h, h, 16, 1, 1, hu.stream())
+    call("rsu_conv2d_fwd", srcs, 2, hu.ptr(wp), None, hu.ptr(y), N, h, h, 16, 1, 1, 0, hu.stream())
     ref = U.conv2d_fwd(np.concatenate([U.center_crop(a, h, h), c], axis=3), hu.q(W), None, relu=True)
     hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd 16+16")
 
@@ -98,16 +98,16 @@ def test_conv2d_bwd_data(N, H, W, Cin, Cout, dil):
     wp = hu.pack_conv_bwd(w)
     dzd, yd = hu.dev_bf16(dz), hu.dev_bf16(yprev)
     dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), hu.ptr(yd), 0, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), hu.ptr(yd), 0, N, H, W, Cin, 0, Cin, Cout, dil, 0, hu.stream())
     ref = U.relu_bwd(yprev, U.conv2d_bwd_data(dz, hu.q(w), (H, W), dil=dil))
     hu.assert_bf16_close(hu.host(dx), ref, "conv2d_bwd_data+relu mask")
     # no mask, then accumulate a second time: dx = q(q(g) + g)
     dx2 = torch.zeros((N, H, W, Cin), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 0, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 0, N, H, W, Cin, 0, Cin, Cout, dil, 0, hu.stream())
     g = U.conv2d_bwd_data(dz, hu.q(w), (H, W), dil=dil)
     hu.assert_bf16_close(hu.host(dx2), g, "conv2d_bwd_data")
     first = hu.host(dx2).copy()
-    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 1, N, H, W, Cin, 0, Cin, Cout, dil, hu.stream())
+    call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx2), None, 1, N, H, W, Cin, 0, Cin, Cout, dil, 0, hu.stream())
     hu.assert_bf16_close(hu.host(dx2), first + g, "conv2d_bwd_data accumulate", ulps=2.0)
 
 
@@ -122,7 +122,7 @@ def test_conv2d_bwd_data_source_slice():
         wp = hu.pack_conv_bwd(w, off, cnt)
         dx = torch.zeros((N, H, H, cnt), dtype=torch.bfloat16, device=hu.DEV)
         dzd = hu.dev_bf16(dz)
-        call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), None, 0, N, H, H, cnt, 0, cnt, Cout, 1, hu.stream())
+        call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), None, 0, N, H, H, cnt, 0, cnt, Cout, 1, 0, hu.stream())
         hu.assert_bf16_close(hu.host(dx), full[..., off:off + cnt], "bwd_data slice %d" % off)
 
 
@@ -141,7 +141,7 @@ def test_conv2d_bwd_weight_and_bias(N, H, W, Cin, Cout, dil):
     ws[nws:] = 12345.0  # guard band: the kernels must stay inside the advertised workspace
     s = hu.src_of(xd, H, W)
     db2 = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
-    call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db2), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, hu.stream())
+    call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db2), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, dil, 0, hu.stream())
     ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=dil)
     hu.assert_f32_close(hu.host(dw), ref_dw, "conv2d_bwd_weight")
     hu.assert_f32_close(hu.host(db2), ref_db, "bias grad fused in wgrad")
@@ -167,7 +167,7 @@ def test_pingpong_wgrad_gives_the_bits_of_igemm_wgrad(N, H, W, Cin, Cout, monkey
         db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
         ws = torch.zeros(nws, dtype=torch.float32, device=hu.DEV)
         s = hu.src_of(xd, H, W)
-        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, hu.stream())
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, 0, hu.stream())
         out[gen] = (hu.host(dw), hu.host(db))
     assert np.array_equal(out["1"][0].view(np.uint32), out["2"][0].view(np.uint32)), "weight gradient bits differ"
     assert np.array_equal(out["1"][1].view(np.uint32), out["2"][1].view(np.uint32)), "bias gradient bits differ"
@@ -190,7 +190,7 @@ def test_pingpong_wgrad_64(N, H, W, Cin, Cout, monkeypatch):
         ws = torch.zeros(nws + 1024, dtype=torch.float32, device=hu.DEV)
         ws[nws:] = 777.0
         s = hu.src_of(xd, H, W)
-        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, hu.stream())
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), hu.ptr(db), hu.ptr(ws), N, Ho, Wo, Cin, 0, Cout, 1, 0, hu.stream())
         assert bool((ws[nws:] == 777.0).all()), "workspace overrun"
         out[v] = (hu.host(dw), hu.host(db))
     ref_dw, ref_db = U.conv2d_bwd_weight(x, dz, dil=1)
@@ -211,7 +211,7 @@ def test_conv2d_bwd_weight_cropped_sources():
     ws = torch.zeros(lib().rsu_conv2d_bwd_weight_ws_floats(96, 32, 64), dtype=torch.float32, device=hu.DEV)
     for t, off in [(ad, 0), (cd, 32)]:
         s = hu.src_of(t, h, h)
-        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), None, hu.ptr(ws), N, h - 2, h - 2, 96, off, 64, 1, hu.stream())
+        call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw), None, hu.ptr(ws), N, h - 2, h - 2, 96, off, 64, 1, 0, hu.stream())
     cat = np.concatenate([U.center_crop(a, h, h), c], axis=3)
     hu.assert_f32_close(hu.host(dw), U.conv2d_bwd_weight(cat, dz)[0], "bwd_weight 2 cropped sources")
 
@@ -245,7 +245,7 @@ def test_color_adjust_and_first_conv(dil, keep):
     y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
     pk1 = torch.zeros(lib().rsu_packed_first_bytes(Cout) // 2, dtype=torch.bfloat16, device=hu.DEV)
     call("rsu_pack_conv_first", hu.ptr(w1d), hu.ptr(pk1), Cout, hu.stream())
-    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, hu.stream())
+    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, 0, hu.stream())
     ref = U.conv2d_fwd(got16[..., 0:3], hu.q(w1), b1, dil=dil)
     hu.assert_bf16_close(hu.host(y), ref, "conv_first_fwd")
     # weight gradients (MFMA narrow wgrad over the 16-channel tensor)
@@ -255,7 +255,7 @@ def test_color_adjust_and_first_conv(dil, keep):
     ws = torch.zeros(lib().rsu_conv_first_bwd_ws_floats(Cout), dtype=torch.float32, device=hu.DEV)
     dzd = hu.dev_bf16(dz)
     dbf = torch.zeros(Cout, dtype=torch.float32, device=hu.DEV)
-    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gx), hu.ptr(dbf), hu.ptr(ws), N, H, W, Cout, dil, hu.stream())
+    call("rsu_conv_first_bwd_weight", hu.ptr(in16), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gx), hu.ptr(dbf), hu.ptr(ws), N, H, W, Cout, dil, 0, hu.stream())
     hu.assert_f32_close(hu.host(dbf), dz.reshape(-1, Cout).astype(np.float64).sum(0), "conv_first db")
     hu.assert_f32_close(hu.host(dw1), U.conv2d_bwd_weight(got16[..., 0:3], dz, dil=dil)[0], "conv_first dW")
     ref_gx = U.conv2d_bwd_weight(got16[..., 4:16], dz, dil=dil)[0].reshape(9, 12, Cout)  # rows: 9 masked (x-0.5) products, 3 mask sums
@@ -342,12 +342,12 @@ def test_convT(N, H, W, Cin, Cout):
     xd = hu.dev_bf16(x)
     y = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
     bd = hu.dev_f32(b)
-    call("rsu_convT2x2_fwd", hu.ptr(xd), hu.ptr(pf), hu.ptr(bd), hu.ptr(y), N, H, W, Cin, Cout, hu.stream())
+    call("rsu_convT2x2_fwd", hu.ptr(xd), hu.ptr(pf), hu.ptr(bd), hu.ptr(y), N, H, W, Cin, Cout, 0, hu.stream())
     hu.assert_bf16_close(hu.host(y), U.convT_fwd(x, hu.q(K), b), "convT fwd")
     dy = hu.q(_rand(rng, N, 2 * H, 2 * W, Cout, scale=0.1))
     dyd = hu.dev_bf16(dy)
     dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xd), 1.0, N, H, W, Cin, Cout, hu.stream())
+    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xd), 1.0, N, H, W, Cin, Cout, 0, hu.stream())
     rdx, rdK, rdb = U.convT_bwd(x, hu.q(K), dy)
     hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx), "convT bwd_data")
     # dropout in front of the transposed conv (unet.py:64-65): forward kernel + backward fused as (mask source, scale)
@@ -357,12 +357,12 @@ def test_convT(N, H, W, Cin, Cout):
     call("rsu_dropout_fwd", hu.ptr(xd), hu.ptr(xdrop), x.size, keep, key, hu.stream())
     m = U.dropout_mask(x.shape, keep, key)
     np.testing.assert_array_equal(hu.host(xdrop), hu.q(x * m * inv))
-    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xdrop), float(inv), N, H, W, Cin, Cout, hu.stream())
+    call("rsu_convT2x2_bwd_data", hu.ptr(dyd), hu.ptr(pb), hu.ptr(dx), hu.ptr(xdrop), float(inv), N, H, W, Cin, Cout, 0, hu.stream())
     hu.assert_bf16_close(hu.host(dx), U.relu_bwd(x, rdx * m * inv), "convT bwd_data with dropout")
     dK = torch.full((2, 2, Cout, Cin), float("nan"), dtype=torch.float32, device=hu.DEV)
     ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(Cin, Cout), dtype=torch.float32, device=hu.DEV)
     dbT = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
-    call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(dbT), hu.ptr(ws), N, H, W, Cin, Cout, hu.stream())
+    call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(dbT), hu.ptr(ws), N, H, W, Cin, Cout, 0, hu.stream())
     hu.assert_f32_close(hu.host(dK), rdK, "convT bwd_weight")
     hu.assert_f32_close(hu.host(dbT), rdb, "convT bias grad fused in bwd_weight")
 
@@ -447,46 +447,3 @@ def test_abi_rejects_bad_geometry():
     o = ctypes.c_int()
     assert lib().rsu_input_size_needed(128, 5, ctypes.byref(o)) == -22
     assert lib().rsu_extract_tiles(None, None, 1, 20, 12, 8, 5, 0, 1, None) == -22
-
-
-@pytest.mark.parametrize("gen", [2, 4])
-@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(2, 45, 52, 64, 96, 1), (1, 70, 66, 32, 128, 1), (1, 40, 40, 64, 64, 2)])
-def test_one_bit_relu_masks(gen, N, H, W, Cin, Cout, dil):
-    """rsu_conv2d_fwd_bits emits (y > 0) as one bit per element beside y; rsu_conv2d_bwd_data_bits with those bits equals
-    rsu_conv2d_bwd_data with the bf16 activation as relu_src, bit for bit (both conv generations; dilated convs run igemm_fwd2)"""
-    import os
-    old = os.environ.get("RSU_FWD_GEN")
-    os.environ["RSU_FWD_GEN"] = str(gen)
-    try:
-        rng = np.random.RandomState(N + H + Cout + dil)
-        x = hu.q(rng.standard_normal((N, H, W, Cin)).astype(np.float32))
-        w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
-        b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
-        xd, wp, bd = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b)
-        Ho, Wo = H - 2 * dil, W - 2 * dil
-        s = (RsuSrc * 1)(hu.src_of(xd, H, W))
-        y0 = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-        y1 = torch.full_like(y0, float("nan"))
-        nb = lib().rsu_relu_bits_bytes(N, Ho, Wo, Cout)
-        bits = torch.full((nb,), 0xAA, dtype=torch.uint8, device=hu.DEV)
-        call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y0), N, H, W, Cout, dil, 1, hu.stream())
-        call("rsu_conv2d_fwd_bits", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y1), hu.ptr(bits), N, H, W, Cout, dil, hu.stream())
-        assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
-        want = np.packbits((hu.host(y1) > 0).reshape(N, Ho, Wo, Cout // 8, 8), axis=-1, bitorder="little").reshape(-1)
-        np.testing.assert_array_equal(bits.cpu().numpy(), want)
-        # the next layer's backward-data: dz over the conv output (Cout2 channels) -> gradient of y, masked by (y > 0)
-        Cout2 = 64
-        w2 = (rng.standard_normal((3, 3, Cout, Cout2)) / np.sqrt(9 * Cout)).astype(np.float32)
-        dz = hu.dev_bf16(hu.q((rng.standard_normal((N, Ho - 2 * dil, Wo - 2 * dil, Cout2)) * 0.1).astype(np.float32)))
-        wb = hu.pack_conv_bwd(w2, 0, Cout)
-        d0 = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-        d1 = torch.full_like(d0, float("nan"))
-        call("rsu_conv2d_bwd_data", hu.ptr(dz), hu.ptr(wb), hu.ptr(d0), hu.ptr(y1), 0, N, Ho, Wo, Cout, 0, Cout, Cout2, dil, hu.stream())
-        call("rsu_conv2d_bwd_data_bits", hu.ptr(dz), hu.ptr(wb), hu.ptr(d1), hu.ptr(bits), N, Ho, Wo, Cout, Cout2, dil, hu.stream())
-        assert torch.equal(d0.view(torch.int16), d1.view(torch.int16))
-        assert float((hu.host(d1) != 0).mean()) > 0.2
-    finally:
-        if old is None:
-            os.environ.pop("RSU_FWD_GEN", None)
-        else:
-            os.environ["RSU_FWD_GEN"] = old

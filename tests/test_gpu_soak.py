@@ -83,8 +83,11 @@ def test_measured_tile_shapes_do_not_change_the_numbers():
     from road_segmentation_unet_amd.unet import UNet
 
     def run(tune):
-        call("rsu_set_autotune", 1 if tune else 0)
+        call("rsu_set_autotune", 1 if tune else 0)   # RSU_TUNE_LOOKUP / RSU_TUNE_OFF
         m = UNet(4, 32, False, 2, 204, seed=5, training=True)
+        if tune:
+            m.tune()   # the explicit tuning pass: the only place where shapes are measured
+            assert lib().rsu_get_autotune() == 1
         g = torch.Generator(device="cpu").manual_seed(9)
         for _ in range(3):
             m.x.copy_(torch.rand((2, m.S, m.S, 3), generator=g))

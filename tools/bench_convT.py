@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--gens", default="1,2")
     a = ap.parse_args()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call("rsu_set_autotune", 2)   # developer tool: measure tile shapes at first sight (RSU_TUNE_MEASURE)
     h = input_size_needed(a.P, a.L)
     for _ in range(a.L - 1):
         h = (h - 4) // 2
@@ -66,9 +67,9 @@ def main():
         line = "up_conv_%d  H %3d C %4d->%4d %6.1f GF |" % (i, h, cin, cout, fl / 1e9)
         for gen in a.gens.split(","):
             os.environ["RSU_CT_GEN"] = gen
-            for op, fn in [("fwd", lambda: call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), a.B, h, h, cin, cout, st)),
-                           ("bwd", lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, a.B, h, h, cin, cout, st)),
-                           ("wg", lambda: call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), ptr(db), ptr(ws), a.B, h, h, cin, cout, st))]:
+            for op, fn in [("fwd", lambda: call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), a.B, h, h, cin, cout, 0, st)),
+                           ("bwd", lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, a.B, h, h, cin, cout, 0, st)),
+                           ("wg", lambda: call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), ptr(db), ptr(ws), a.B, h, h, cin, cout, 0, st))]:
                 if op == "wg" and gen != a.gens.split(",")[0]:
                     continue
                 t = timeit(fn)

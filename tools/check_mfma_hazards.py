@@ -148,17 +148,9 @@ def walk(ins, labels, start, budget, visit):
             stack.append((s, el + ins[j].ws()))
 
 
-# Timing-ablation builds (igemm_wgpp's DBG != 0 instantiations: kernels that skip their reads, MFMAs or staging to time the rest) are
-# not checked: they produce no results, and with their loops hollowed out the compiler lays the two wave groups' code out behind
-# exec-mask branches whose never-taken fall-through edges read as hazards.
-SKIP = re.compile(r"igemm_wgpp_kernelILi\dELi[1-9]\d*E")
-
-
 def check(path):
     bad = 0
     for name, ins, labels in kernels(path):
-        if SKIP.search(name):
-            continue
         n_mfma = n_store = 0
         for i, I in enumerate(ins):
             if I.is_mfma() and not I.asm:

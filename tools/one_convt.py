@@ -23,9 +23,9 @@ dK = torch.zeros_like(K)
 ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(cin, cout), device=DEV)
 for _ in range(5):
     if op == "fwd":
-        call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, st)
+        call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, 0, st)
     elif op == "bwd":
-        call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, st)
+        call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, 0, st)
     else:
-        call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), None, ptr(ws), B, h, h, cin, cout, st)
+        call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), None, ptr(ws), B, h, h, cin, cout, 0, st)
 torch.cuda.synchronize()

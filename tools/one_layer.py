@@ -31,9 +31,9 @@ src = RsuSrc(x.data_ptr(), H, H, cin, 0, 0)
 arr = (RsuSrc * 1)(src)
 for _ in range(reps):
     if op == "fwd":
-        call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, H, H, cout, dil, 1, st)
+        call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, H, H, cout, dil, 1, 0, st)
     elif op == "bwd":
-        call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, H, H, cin, 0, cin, cout, dil, st)
+        call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, H, H, cin, 0, cin, cout, dil, 0, st)
     else:
-        call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, st)
+        call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), None, ptr(ws), B, ho, ho, cin, 0, cout, dil, 0, st)
 torch.cuda.synchronize()

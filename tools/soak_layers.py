@@ -83,11 +83,11 @@ def main():
         arr = (RsuSrc * 1)(src)
         tag = "%s H%d %d->%d" % (name, hin, cin, cout)
         if "fwd" in ops:
-            tot += soak(tag + " fwd", lambda: call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, st), [y], args.reps)
+            tot += soak(tag + " fwd", lambda: call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, 0, st), [y], args.reps)
         if "bwd" in ops:
-            tot += soak(tag + " bwd", lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, st), [dx], args.reps)
+            tot += soak(tag + " bwd", lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, 0, st), [dx], args.reps)
         if "wg" in ops:
-            tot += soak(tag + " wg", lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, st), [dw, db], args.reps)
+            tot += soak(tag + " wg", lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, 0, st), [dw, db], args.reps)
     for name, h, cin, cout in convt_layers(args.L, args.root, args.P):
         if args.only and args.only not in name:
             continue
@@ -104,11 +104,11 @@ def main():
         ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(cin, cout), device=DEV)
         tag = "%s H%d %d->%d" % (name, h, cin, cout)
         if "tfwd" in ops:
-            tot += soak(tag + " tfwd", lambda: call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, st), [y], args.reps)
+            tot += soak(tag + " tfwd", lambda: call("rsu_convT2x2_fwd", ptr(x), ptr(pf), ptr(b), ptr(y), B, h, h, cin, cout, 0, st), [y], args.reps)
         if "tbwd" in ops:
-            tot += soak(tag + " tbwd", lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, st), [dx], args.reps)
+            tot += soak(tag + " tbwd", lambda: call("rsu_convT2x2_bwd_data", ptr(dy), ptr(pb), ptr(dx), ptr(x), 1.0, B, h, h, cin, cout, 0, st), [dx], args.reps)
         if "twg" in ops:
-            tot += soak(tag + " twg", lambda: call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), ptr(db), ptr(ws), B, h, h, cin, cout, st), [dK, db], args.reps)
+            tot += soak(tag + " twg", lambda: call("rsu_convT2x2_bwd_weight", ptr(x), ptr(dy), ptr(dK), ptr(db), ptr(ws), B, h, h, cin, cout, 0, st), [dK, db], args.reps)
     print("total bad launches:", tot)
     sys.exit(1 if tot else 0)
 
