@@ -185,6 +185,35 @@ size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout);
  * 32-pixel step); pass it with ONE of the sources of a concatenated input, NULL with the others. */
 int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
                           int Cin_total, int ci_off, int Cout, int dil, int ncu, rsu_stream_t stream);
+/* Grouped weight gradients (new; TensorFlow's executor runs independent Conv2DBackpropFilter ops side by side, tf_aerial_images.py:120-121).
+ * A weight-gradient launch that has the chip to itself writes one fp32 partial result per workgroup -- 75 MB of slabs per layer on
+ * 256 CUs, read back by a reduce launch -- and a layer with few pixels cannot fill the chip. A GROUP runs up to
+ * RSU_WGRAD_GROUP_MAX layers in ONE launch: every layer gets a share of the chip in proportion to its work, the shallow layers are
+ * split over few workgroups (the slabs of the whole group are about one per CU), the deep ones not at all (their workgroups write the
+ * gradient in place), and ONE reduce launch finishes all splits. Results equal those of the single launches up to the summation
+ * order of the pixel splits (fp32 rounding), and are deterministic for a given (jobs, N, ncu).
+ * Usage (the pattern of rsu_pack_table_*): fill a host table with rsu_wgrad_group_plan (the pointers are static for a network, so this
+ * happens once per group and CU budget), copy its rsu_wgrad_group_table_bytes() bytes to the device once, then call
+ * rsu_wgrad_group_run after every backward pass. job.kind selects the fields' meaning:
+ *   RSU_WGRAD_CONV3X3  as rsu_conv2d_bwd_weight: src = the input window, dz [N][Ho][Wo][Cout], dw HWIO rows [ci_off, ci_off+src.C), db optional
+ *   RSU_WGRAD_CONVT2X2 as rsu_convT2x2_bwd_weight: src = {x, H, W, Cin, 0, 0}, dz = dy [N][2H][2W][Cout], dw = dK, db optional
+ * ws: rsu_wgrad_group_ws_floats() floats of scratch, owned by the group between a run and the end of its stream work. */
+#define RSU_WGRAD_CONV3X3 0
+#define RSU_WGRAD_CONVT2X2 1
+#define RSU_WGRAD_GROUP_MAX 16
+typedef struct {
+    int kind;
+    rsu_src_t src;
+    const void* dz;
+    float* dw;
+    float* db;
+    int Ho, Wo;                         /* RSU_WGRAD_CONV3X3: size of dz */
+    int Cin_total, ci_off, Cout, dil;   /* RSU_WGRAD_CONVT2X2 reads Cout only */
+} rsu_wgrad_job_t;
+size_t rsu_wgrad_group_table_bytes(void);
+size_t rsu_wgrad_group_ws_floats(void);
+int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, float* ws, int N, int ncu, void* host_table);
+int rsu_wgrad_group_run(const void* host_table, const void* dev_table, rsu_stream_t stream);
 /* BiasAddGrad: db[c] = sum over npix of dz[pix][c]. ws: rsu_bias_grad_ws_floats(npix, C) floats. */
 size_t rsu_bias_grad_ws_floats(long npix, int C);
 int rsu_bias_grad(const void* dz, float* db, float* ws, long npix, int C, rsu_stream_t stream);

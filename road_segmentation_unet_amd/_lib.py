@@ -16,6 +16,15 @@ class RsuSrc(ctypes.Structure):
     _fields_ = [("ptr", _vp), ("H", _i), ("W", _i), ("C", _i), ("oy", _i), ("ox", _i)]
 
 
+class RsuWgradJob(ctypes.Structure):
+    """rsu_wgrad_job_t: one layer of a grouped weight-gradient launch"""
+    _fields_ = [("kind", _i), ("src", RsuSrc), ("dz", _vp), ("dw", _vp), ("db", _vp), ("Ho", _i), ("Wo", _i),
+                ("Cin_total", _i), ("ci_off", _i), ("Cout", _i), ("dil", _i)]
+
+
+WGRAD_CONV3X3, WGRAD_CONVT2X2, WGRAD_GROUP_MAX = 0, 1, 16
+
+
 class RsuPlanRow(ctypes.Structure):
     """rsu_plan_row_t"""
     _fields_ = [(n, _i) for n in ("kind", "level", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "dilation", "nsrc")]
@@ -65,6 +74,10 @@ SIGNATURES = {
     "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_wgrad_group_table_bytes": (_sz, []),
+    "rsu_wgrad_group_ws_floats": (_sz, []),
+    "rsu_wgrad_group_plan": (_i, [ctypes.POINTER(RsuWgradJob), _i, _vp, _i, _i, _vp]),
+    "rsu_wgrad_group_run": (_i, [_vp, _vp, _vp]),
     "rsu_bias_grad_ws_floats": (_sz, [_l, _i]),
     "rsu_bias_grad": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "rsu_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _u, _vp]),

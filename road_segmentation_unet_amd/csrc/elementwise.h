@@ -22,6 +22,15 @@ hipError_t ew_colsum(const void* dz, float* db, float* ws, long npix, int C, hip
 // out2 (optional): n2 more float4 items behind the taps of every slab, reduced into out2 by the same launch
 hipError_t ew_reduce_slabs(const float* slab, float* out, float* out2, int n2, int nsplit, long slab_elems, int ntap, int CsOut, int cs_off, int cs_cnt,
                            int CfOut, hipStream_t st);
+// grouped form: one launch reduces the slabs of several weight-gradient jobs (device-resident job table)
+struct ReduceJob {
+    const float* slab; float* out; float* out2;
+    long slab_elems;
+    int n2, nsplit, ntap, CsOut, cs_off, cs_cnt, CfOut;
+    int block_begin, wide, pad_;
+};
+int ew_reduce_job_blocks(ReduceJob& j);   // sets j.wide, returns the workgroups the job needs
+hipError_t ew_reduce_slabs_many(const ReduceJob* jobs_dev, int njobs, int total_blocks, hipStream_t st);
 int ew_head_blocks(long npix, int C);
 hipError_t ew_head(bool train, const void* act, const float* w, const float* b, const int64_t* labels, float* prob, float* logits, void* dact, float* dw,
                    float* db, float* loss_sum, float* ws, long npix, int C, float inv_count, hipStream_t st);

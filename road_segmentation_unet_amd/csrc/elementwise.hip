@@ -319,6 +319,41 @@ __global__ void __launch_bounds__(256) k_reduce_slabs_wide(const float* __restri
     }
 }
 
+// the slab reductions of a whole group of weight-gradient launches (igemm_wg_group) in ONE launch: block b serves job r with
+// block_begin[r] <= b < block_begin[r+1]; per job either form above (wide: 32 outputs x 8 split lanes per block), same summation
+// orders as the single launches
+__global__ void __launch_bounds__(256) k_reduce_slabs_many(const ReduceJob* __restrict__ jobs, int njobs) {
+    __shared__ f32x4 red[256];
+    int r = 0;
+    while (r + 1 < njobs && (int)blockIdx.x >= jobs[r + 1].block_begin) ++r;
+    const ReduceJob J = jobs[r];
+    const int b = blockIdx.x - J.block_begin;
+    const long total = (long)J.ntap * J.cs_cnt * (J.CfOut >> 2);
+    ReduceItem it;
+    if (J.wide) {
+        const int el = threadIdx.x & 31, zp = threadIdx.x >> 5;
+        const long tid = (long)b * 32 + el;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        const bool have = reduce_item(it, tid, total, J.out, J.out2, J.n2, J.ntap, J.CsOut, J.cs_off, J.cs_cnt, J.CfOut);
+        if (have)
+            for (int z = zp; z < J.nsplit; z += 8) t += *(const f32x4*)(J.slab + z * J.slab_elems + it.e);
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (zp == 0 && have) {
+            f32x4 q = red[el];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) q += red[k * 32 + el];
+            *(f32x4*)it.dst = q;
+        }
+    } else {
+        const long tid = (long)b * 256 + threadIdx.x;
+        if (!reduce_item(it, tid, total, J.out, J.out2, J.n2, J.ntap, J.CsOut, J.cs_off, J.cs_cnt, J.CfOut)) return;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < J.nsplit; ++z) t += *(const f32x4*)(J.slab + z * J.slab_elems + it.e);
+        *(f32x4*)it.dst = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // head: 1x1 conv (C -> 2) + softmax[...,1] (+ mean CE loss and its backward)
 // LP = C/8 lanes per pixel, partial logits reduced with wave shuffles
@@ -757,6 +792,15 @@ hipError_t ew_reduce_slabs(const float* slab, float* out, float* out2, int n2, i
     else
         hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total, 256)), dim3(256), 0, st, slab, out, out2, n2, nsplit, slab_elems, ntap, CsOut,
                            cs_off, cs_cnt, CfOut);
+    return hipGetLastError();
+}
+int ew_reduce_job_blocks(ReduceJob& j) {
+    const long total = (long)j.ntap * j.cs_cnt * (j.CfOut / 4) + (j.out2 ? j.n2 : 0);
+    j.wide = j.nsplit >= 16 ? 1 : 0;
+    return (int)(j.wide ? (total + 31) / 32 : (total + 255) / 256);
+}
+hipError_t ew_reduce_slabs_many(const ReduceJob* jobs_dev, int njobs, int total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_slabs_many, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
     return hipGetLastError();
 }
 int ew_head_blocks(long npix, int C) {

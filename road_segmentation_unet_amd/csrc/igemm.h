@@ -108,6 +108,27 @@ int igemm_wgrad_csb(int cfg);  // S channels per workgroup (grid.y block)
 int igemm_wgrad_kgroups(int cfg);  // slabs written per grid.z slice
 hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,
                               hipStream_t st);
+// the grouped launch (igemm_wgpp.hip, igemm_wg_group_kernel): up to IGW_GROUP_MAX layers' weight gradients in one launch
+enum { IGW_FAM_WGPP3 = 0, IGW_FAM_WGPP4 = 1, IGW_FAM_WGPP5 = 2, IGW_FAM_WGPP6 = 3, IGW_FAM_WGP64_4 = 4, IGW_FAM_WGP64_5 = 5,
+       IGW_FAM_GENERIC = 8 /* + 2 * cfg + (ntap == 4) */ };
+#define IGW_GROUP_MAX 16
+#define IGW_UNITS_MAX 2048
+struct IgWgJob {
+    IgWgradParams p;
+    int gx, gy, gz;   // units of the job: F channel blocks x S channel blocks x pixel splits (gz == p.nsplit)
+    int family;       // IGW_FAM_*
+    int pad_;
+};
+struct IgWgGroupParams {
+    int njobs, nwg;
+    IgWgJob job[IGW_GROUP_MAX];
+    int wg_first[257];              // workgroup b runs unit[wg_first[b] .. wg_first[b+1])
+    unsigned unit[IGW_UNITS_MAX];   // (job << 24) | unit index inside the job
+};
+int igemm_wg_group_family(int cfg, int ntap, const IgWgradParams& p);
+size_t igemm_wg_group_lds_bytes(int family, const IgWgradParams& p);
+#define IGW_GROUP_LDS_BYTES (160 * 1024)   // the grouped launch always takes the whole LDS: its last 256 bytes hold the loop state, the rest is the unit's
+hipError_t igemm_wg_group_launch(const IgWgGroupParams* dev_table, int nwg_total, hipStream_t st);
 // ping-pong wave groups (igemm_wgpp.hip): the 128x64 shape of the 3x3 stride-1 weight gradient, same slabs and bits as igemm_wgrad
 bool igemm_wgpp_supports(int cfg, int ntap, const IgWgradParams& p);
 bool igemm_wgp64_supports(int cfg, int ntap, const IgWgradParams& p);

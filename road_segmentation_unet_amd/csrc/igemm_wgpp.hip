@@ -16,7 +16,7 @@
 // G1's R(3) / behind G0's MFMAs of M(3) -- the same global interval, whose barrier publishes the tile to G0's next R(0).
 #include <type_traits>
 
-#include "igemm.h"
+#include "igemm_wgrad_body.h"
 
 #define RSU_SENT 0x80000000u
 
@@ -40,8 +40,11 @@ __device__ __forceinline__ void bdma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
 
 // DBG (timing ablations, RSU_WG_DBG): 1 = no staging after the first tile, 2 = no LDS reads, 4 = no MFMAs, 8 = S reads of taps 0-2 only
 // SCH: phases per k-step and where its taps are split (sched_nph)
-template <int LSW, int DBG, int SCH>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgpp_kernel(const IgWgradParams p) {
+// (the kernel body as a device function: `lds` = the workgroup's dynamic LDS, (cfb, csb, z) = the unit it works on; igemm_wgpp_kernel
+// calls it once per workgroup, the grouped launch igemm_wg_group_kernel once per unit of its workgroup's list)
+template <int LSW, int DBG, int SCH, class P>
+__device__ __forceinline__ void igemm_wgpp_body(const P& p, __attribute__((address_space(3))) char* lds, const int cfb, const int csb,
+                                                const int z, const unsigned tid) {
     constexpr int NW = 8, NTAP = 9, KW = 3, TMK = 128, CFT = 4;
     constexpr int SW = 1 << LSW, TR = TMK >> LSW;
     constexpr int CW = (SW + 2 + 7) / 8 * 8;
@@ -51,17 +54,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int FPL = TMK * 128, FBUF = 2 * FPL, SBUF = NSW * NW * 1024;
     constexpr int SLOT = FBUF + SBUF;                      // LDS: [F tile | S halo tile] x 2 slots
     static_assert(2 * SLOT <= 160 * 1024 && NFW + NSW <= 9, "staging budget");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wcs = wave & 3;   // wcf == grp
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
-    // (cfb, csb, z) from an XCD-contiguous numbering: the gx * gy workgroups of one pixel split z read the same F and S pixel tiles
-    // (each F tile gy times, each S tile gx times) -- on one XCD all but the first of those reads are L2 hits
-    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
-    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y);
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     // (the S window is the F image plus a border of one: 3x3 taps, stride 1, dilation 1)
 
@@ -372,8 +369,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 // stream never ends: behind the last tile it stages that tile again into a slot nobody reads, so the counts always hold.
 // The summation order differs from igemm_wgrad's 64x64 shape (which split the k-steps over its wave groups): results agree to fp32
 // rounding, not bit for bit.
-template <int LSW>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgp64_kernel(const IgWgradParams p) {
+template <int LSW, class P>
+__device__ __forceinline__ void igemm_wgp64_body(const P& p, __attribute__((address_space(3))) char* lds, const int cfb, const int csb,
+                                                 const int z, const unsigned tid) {
     constexpr int NW = 8, KW = 3, TMK = 128, CFT = 4;
     constexpr int SW = 1 << LSW, TR = TMK >> LSW;
     constexpr int CW = (SW + 2 + 7) / 8 * 8;
@@ -383,15 +381,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int NP = NFW + NSW;
     constexpr int FBUF = TMK * 128, SBUF = NSW * NW * 1024, SLOT = FBUF + SBUF, NSLOT = 3;
     static_assert(NSLOT * SLOT <= 160 * 1024, "staging budget");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wcs = wave & 3;
     const int g4 = lane >> 4, l15 = lane & 15, q4 = l15 >> 2, p4 = lane & 3;
-    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
-    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y);
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     auto sgpr = [](auto v) { return __builtin_amdgcn_readfirstlane(v); };
 
@@ -646,6 +640,127 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         bar();  // G0 sits out G1's last M interval
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's last pieces: nothing may land in this workgroup's LDS after it has gone
+}
+
+// ---------------------------------------------------------------------------------------------
+// one launch per layer: (cfb, csb, z) from an XCD-contiguous numbering -- the gx * gy workgroups of one pixel split z read the same F
+// and S pixel tiles (each F tile gy times, each S tile gx times): on one XCD all but the first of those reads are L2 hits
+#define WG_UNIT_FROM_GRID()                                                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                                                              \
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;                                             \
+    const int lid = xcd_contiguous_id(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);  \
+    const int cfb = lid % gridDim.x, csb = (lid / gridDim.x) % gridDim.y, z = lid / (gridDim.x * gridDim.y)
+template <int LSW, int DBG, int SCH>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgpp_kernel(const IgWgradParams p) {
+    WG_UNIT_FROM_GRID();
+    igemm_wgpp_body<LSW, DBG, SCH>(p, lds, cfb, csb, z, threadIdx.x);
+}
+template <int LSW>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wgp64_kernel(const IgWgradParams p) {
+    WG_UNIT_FROM_GRID();
+    igemm_wgp64_body<LSW>(p, lds, cfb, csb, z, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// igemm_wg_group: the weight gradients of SEVERAL layers in one launch. A layer launched alone on 256 CUs writes one fp32 partial
+// result (a 128 x 64 x 9 slab, 295 KB) per workgroup whatever its size -- 75 MB per layer, read back by the reduce kernel -- and a
+// layer with few pixel tiles leaves part of the chip idle. Here every layer (job) gets a share of the workgroups in proportion to its
+// work (rsu_api.hip plans it): few pixel splits for the shallow layers (the slabs of the WHOLE group are about one per CU), none for the
+// deep ones, whose (channel block) units reduce over all pixels and write the gradient in place.
+// A unit u < gx * gy * gz of job j is (cfb, csb, z) = (u % gx, (u / gx) % gy, u / (gx * gy)). The launch is PERSISTENT -- exactly one
+// workgroup per budgeted CU, so that it keeps to its share of the chip beside the other stream's kernel -- and workgroup b walks the
+// units unit[wg_first[b] .. wg_first[b+1]) the planner dealt to it (longest-first greedy: every workgroup gets about the same work).
+// The unit bodies are the very kernels above (families: igemm_wgpp per strip width, igemm_wgp64, and the generic igemm_wgrad shapes for the 2x2
+// stride-2 taps of the transposed convs, dilated convs and the 16-channel input of level 0).
+template <int FAM, class P>
+__device__ __forceinline__ void wg_group_unit(const P& p, __attribute__((address_space(3))) char* lds, int cfb, int csb, int z, unsigned tid) {
+    if constexpr (FAM == IGW_FAM_WGPP3) igemm_wgpp_body<3, 0, 4>(p, lds, cfb, csb, z, tid);
+    else if constexpr (FAM == IGW_FAM_WGPP4) igemm_wgpp_body<4, 0, 4>(p, lds, cfb, csb, z, tid);
+    else if constexpr (FAM == IGW_FAM_WGPP5) igemm_wgpp_body<5, 0, 4>(p, lds, cfb, csb, z, tid);
+    else if constexpr (FAM == IGW_FAM_WGPP6) igemm_wgpp_body<6, 0, 4>(p, lds, cfb, csb, z, tid);
+    else if constexpr (FAM == IGW_FAM_WGP64_4) igemm_wgp64_body<4>(p, lds, cfb, csb, z, tid);
+    else if constexpr (FAM == IGW_FAM_WGP64_5) igemm_wgp64_body<5>(p, lds, cfb, csb, z, tid);
+    else {
+        constexpr int CFG = (FAM - IGW_FAM_GENERIC) >> 1, NTAP = ((FAM - IGW_FAM_GENERIC) & 1) ? 4 : 9, KW = NTAP == 4 ? 2 : 3;
+        using C = WgCfg<CFG>;
+        igemm_wgrad_body<C::WCF, C::WCS, C::CFT, C::CST, NTAP, KW, C::TMK, C::KG>(p, lds, cfb, csb, z, tid);
+    }
+}
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) igemm_wg_group_kernel(const IgWgGroupParams* table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) char* lds = (__attribute__((address_space(3))) char*)smem;
+    // persistent: one workgroup per budgeted CU walks the unit list the planner made for it (longest units first).
+    // The loop state -- position in the list, its end, the table pointer -- lives in LDS (one 16-byte slot per wave in the last 256
+    // bytes of the 160 KiB, which no unit body uses; IGW_GROUP_LDS_BYTES) and is read back through an opaque asm at the top of every
+    // iteration: the unit bodies run at the limit of both register files, and four scalars carried across them in registers cost
+    // 60 spilled vector registers in the tightest one.
+    {
+        const unsigned state = IGW_GROUP_LDS_BYTES - 256 + (threadIdx.x >> 6) * 16;
+        const u32x4 st0 = {(unsigned)__ldg(&table->wg_first[blockIdx.x]), (unsigned)__ldg(&table->wg_first[blockIdx.x + 1]),
+                           (unsigned)(uintptr_t)table, (unsigned)((uintptr_t)table >> 32)};
+        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(state), "v"(st0) : "memory");
+    }
+    for (;;) {
+        // (the thread id through an opaque asm, once per iteration: otherwise the compiler hoists everything the unit bodies derive from
+        // it -- lane, wave, LDS offsets -- out of the loop and keeps it in registers across bodies that have none to spare)
+        unsigned tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const unsigned state = IGW_GROUP_LDS_BYTES - 256 + (tid >> 6) * 16;
+        u32x4 st;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(st) : "v"(state) : "memory");
+        const int i = __builtin_amdgcn_readfirstlane((int)st[0]), iend = __builtin_amdgcn_readfirstlane((int)st[1]);
+        if (i >= iend) break;
+        {
+            const unsigned nxt = (unsigned)i + 1u;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(state), "v"(nxt) : "memory");   // (every lane of the wave: same word, same value)
+        }
+        // the job table is read through the constant address space (scalar loads, like kernel arguments): it is written once, when the
+        // group is planned, and never while a launch that reads it is in flight
+        typedef const __attribute__((address_space(4))) IgWgGroupParams* CTab;
+        CTab g = (CTab)(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)st[3]) << 32) | (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)st[2]));
+        const unsigned e = g->unit[i];
+        const int j = (int)(e >> 24), u = (int)(e & 0xffffffu);
+        const int gx = g->job[j].gx, gy = g->job[j].gy, family = g->job[j].family;
+        const int cfb = u % gx, csb = (u / gx) % gy, z = u / (gx * gy);
+        const auto& p = g->job[j].p;   // (stays in the constant address space: the body loads a field where it uses it, like a kernel argument)
+        switch (family) {
+#define WGG_CASE(F) case F: wg_group_unit<F>(p, lds, cfb, csb, z, tid); break;
+            WGG_CASE(IGW_FAM_WGPP3) WGG_CASE(IGW_FAM_WGPP4) WGG_CASE(IGW_FAM_WGPP5) WGG_CASE(IGW_FAM_WGPP6)
+            WGG_CASE(IGW_FAM_WGP64_4) WGG_CASE(IGW_FAM_WGP64_5)
+            WGG_CASE(IGW_FAM_GENERIC + 2 * IGW_CFG_64x64 + 1)   // (the 9-tap 64x64 generic shape spills registers: it stays a launch of its own)
+            WGG_CASE(IGW_FAM_GENERIC + 2 * IGW_CFG_64x16)
+            WGG_CASE(IGW_FAM_GENERIC + 2 * IGW_CFG_128x64) WGG_CASE(IGW_FAM_GENERIC + 2 * IGW_CFG_128x64 + 1)
+#undef WGG_CASE
+        }
+        // a unit leaves nothing in flight (every body ends behind s_waitcnt vmcnt(0)); the barrier keeps a fast wave's staging of the
+        // next unit out of LDS the slowest wave still reads
+        __syncthreads();
+    }
+}
+// family of a planned launch (the kernel the single-layer path would pick), or -1
+int igemm_wg_group_family(int cfg, int ntap, const IgWgradParams& p) {
+    if (igemm_wgpp_supports(cfg, ntap, p)) return IGW_FAM_WGPP3 + (p.lsw - 3);
+    if (igemm_wgp64_supports(cfg, ntap, p)) return p.lsw == 4 ? IGW_FAM_WGP64_4 : IGW_FAM_WGP64_5;
+    if (ntap == 9 && cfg != IGW_CFG_64x64) return IGW_FAM_GENERIC + 2 * cfg;
+    if (ntap == 4 && cfg != IGW_CFG_64x16) return IGW_FAM_GENERIC + 2 * cfg + 1;
+    return -1;
+}
+// dynamic LDS a job of this family needs (the launch asks for the largest of its jobs)
+size_t igemm_wg_group_lds_bytes(int family, const IgWgradParams& p) {
+    const size_t nsw = (size_t)(((p.g.npix_max + 7) / 8 + 7) / 8);
+    if (family >= IGW_FAM_WGPP3 && family <= IGW_FAM_WGPP6) return 2 * (2 * 128 * 128 + nsw * 8 * 1024);
+    if (family == IGW_FAM_WGP64_4 || family == IGW_FAM_WGP64_5) return 3 * (128 * 128 + nsw * 8 * 1024);
+    return igemm_wgrad_lds_bytes((family - IGW_FAM_GENERIC) >> 1, p.g.npix_max, p.nbuf);
+}
+hipError_t igemm_wg_group_launch(const IgWgGroupParams* dev_table, int nwg_total, hipStream_t st) {
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_wg_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IGW_GROUP_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(igemm_wg_group_kernel, dim3(nwg_total), dim3(512), IGW_GROUP_LDS_BYTES, st, dev_table);
+    return hipGetLastError();
 }
 
 template <int LSW>

@@ -5,8 +5,11 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cstddef>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "../../include/rsu.h"
 #include "elementwise.h"
@@ -687,10 +690,16 @@ static bool plan_wgrad(WgPlan& pl, int ncu, int cfg, int N, int Hf, int Wf, int 
     return true;
 }
 
-static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
-                     int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu_arg, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
-    const int ncu = launch_ncu(ncu_arg);
-    if (ncu < 0) return RSU_EINVAL;
+// One weight-gradient launch, prepared: kernel shape, geometry, every parameter but the pixel split and the output pointers.
+struct WgPrep {
+    int cfg, ntap, gx, gy, ntiles, extra;   // extra: floats behind the taps of a slab (bias sums)
+    long main_elems;
+    IgWgradParams p;
+    float *out, *db, *dbs;
+    int cs_cnt;
+};
+static int prep_wgrad(WgPrep& w, int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, int CsOut, int CfOut,
+                      int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu, float* db, float* dbs) {
     // 32-bit byte offsets inside the kernel: both operand tensors must stay below 2 GiB (beyond that the offsets wrapped
     // silently and only the weight gradients came out wrong)
     if ((long)N * Hf * Wf * Cf * 2 >= 0x7ffffff0L || (long)N * S->H * S->W * S->C * 2 >= 0x7ffffff0L) return RSU_E2BIG;
@@ -698,29 +707,19 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     const int wide = wgrad_pick_cfg(cfg, Cf);
     if (wide != cfg && plan_wgrad(pl, ncu, wide, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) cfg = wide;  // else: halo too big for LDS
     else if (!plan_wgrad(pl, ncu, cfg, N, Hf, Wf, Cf, S->C, ntap, ntap / kw, kw, dil, stride)) return RSU_EINVAL;
-    IgWgradParams p;
+    if (db && dbs) return RSU_EINVAL;
+    if (dbs && (CsOut % 4 || cs_off != 0 || S->C != CsOut)) return RSU_EINVAL;
+    IgWgradParams& p = w.p;
     memset(&p, 0, sizeof(p));
     p.F = (const bf16_t*)F;
     p.Hf = Hf; p.Wf = Wf; p.Cf = Cf;
     p.S.ptr = (const bf16_t*)S->ptr;
     p.S.H = S->H; p.S.W = S->W; p.S.C = S->C; p.S.oy = S->oy; p.S.ox = S->ox;
-    const int nslab = pl.nsplit;
-    // a single split needs no slab: its workgroups write the gradient (and the bias sums) in place; otherwise the bias sums are
-    // one more row behind the taps of each slab, so a single reduce launch finishes both
-    const long main_elems = (long)ntap * CsOut * CfOut;
-    // extra items behind the taps of each slab: the F column sums (db, CfOut floats) or the S column sums (dbs, CsOut floats)
-    if (db && dbs) return RSU_EINVAL;
-    const int extra = db ? CfOut : (dbs ? rup(CsOut, 4) : 0);
-    p.slab = nslab == 1 ? out : ws;
-    p.slab_stride = main_elems + extra;
-    p.bslab = db ? (nslab == 1 ? db : ws + main_elems) : nullptr;
-    p.sbslab = dbs ? (nslab == 1 ? dbs : ws + main_elems) : nullptr;
-    if (dbs && (CsOut % 4 || cs_off != 0 || S->C != CsOut)) return RSU_EINVAL;
     p.CsOut = CsOut; p.CfOut = CfOut; p.cs_off = cs_off;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
     p.N = N; p.dil = dil; p.stride = stride;
-    p.nsplit = pl.nsplit;
+    p.nsplit = pl.nsplit;   // the split of a launch that has the chip to itself (finish_wgrad may set another)
     p.ntiles_total = pl.ntiles;
     p.lsw = pl.lsw;
     p.nbuf = pl.nbuf;
@@ -729,15 +728,42 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
     p.dbg = env_int("RSU_WG_DBG", 0);
 #endif
     p.g = pl.g;
+    w.cfg = cfg; w.ntap = ntap; w.gx = pl.gx; w.gy = pl.gy; w.ntiles = pl.ntiles;
+    w.main_elems = (long)ntap * CsOut * CfOut;
+    // extra items behind the taps of each slab: the F column sums (db, CfOut floats) or the S column sums (dbs, CsOut floats)
+    w.extra = db ? CfOut : (dbs ? rup(CsOut, 4) : 0);
+    w.out = out; w.db = db; w.dbs = dbs; w.cs_cnt = S->C;
+    return RSU_OK;
+}
+// the pixel split and where the partial results go: a single split needs no slab -- its workgroups write the gradient (and the bias
+// sums) in place; otherwise the bias sums are one more row behind the taps of each slab, so a single reduce finishes both
+static void finish_wgrad(WgPrep& w, int nsplit, float* ws) {
+    IgWgradParams& p = w.p;
+    p.nsplit = nsplit;
+    p.slab = nsplit == 1 ? w.out : ws;
+    p.slab_stride = w.main_elems + w.extra;
+    p.bslab = w.db ? (nsplit == 1 ? w.db : ws + w.main_elems) : nullptr;
+    p.sbslab = w.dbs ? (nsplit == 1 ? w.dbs : ws + w.main_elems) : nullptr;
+}
+static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu_arg, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
+    const int ncu = launch_ncu(ncu_arg);
+    if (ncu < 0) return RSU_EINVAL;
+    WgPrep w;
+    const int rc = prep_wgrad(w, cfg, F, Hf, Wf, Cf, S, out, CsOut, CfOut, cs_off, N, ntap, kw, dil, stride, ncu, db, dbs);
+    if (rc != RSU_OK) return rc;
+    const int nslab = w.p.nsplit;
+    finish_wgrad(w, nslab, ws);
+    const IgWgradParams& p = w.p;
     // RSU_WG_GEN=1: igemm_wgrad everywhere; default: the ping-pong kernel where it is built (same slabs, same bits)
-    if (env_int("RSU_WG_GEN", 2) >= 2 && igemm_wgpp_supports(cfg, ntap, p))
-        HIP_CHECK_RET(igemm_wgpp_launch(p, pl.gx, pl.gy, pl.nsplit, st));
-    else if (env_int("RSU_WG_GEN", 2) >= 2 && env_int("RSU_WG64", 1) && igemm_wgp64_supports(cfg, ntap, p))
-        HIP_CHECK_RET(igemm_wgp64_launch(p, pl.gx, pl.gy, pl.nsplit, st));
+    if (env_int("RSU_WG_GEN", 2) >= 2 && igemm_wgpp_supports(w.cfg, ntap, p))
+        HIP_CHECK_RET(igemm_wgpp_launch(p, w.gx, w.gy, nslab, st));
+    else if (env_int("RSU_WG_GEN", 2) >= 2 && env_int("RSU_WG64", 1) && igemm_wgp64_supports(w.cfg, ntap, p))
+        HIP_CHECK_RET(igemm_wgp64_launch(p, w.gx, w.gy, nslab, st));
     else
-        HIP_CHECK_RET(igemm_wgrad_launch(cfg, ntap, p, pl.gx, pl.gy, pl.nsplit, st));
+        HIP_CHECK_RET(igemm_wgrad_launch(w.cfg, ntap, p, w.gx, w.gy, nslab, st));
     if (nslab > 1) {
-        HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
+        HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, w.extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
     }
     return RSU_OK;
 }
@@ -779,6 +805,216 @@ extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float
     int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db);
     if (rc) return rc;
     HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));
+    return RSU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped weight gradients (igemm_wg_group_kernel): plan once, run every step
+// ---------------------------------------------------------------------------------------------
+struct WgGroupTable {
+    // device-read part (the caller copies the table to the device once; the kernels read it through the constant address space)
+    IgWgGroupParams g;
+    ReduceJob red[IGW_GROUP_MAX];
+    // host-only part
+    unsigned magic;
+    int nred, red_blocks, nwg_total, nsingle, N, ncu;
+    size_t lds_bytes;
+    rsu_wgrad_job_t single[IGW_GROUP_MAX];   // jobs no grouped kernel body exists for: launched one by one behind the group
+    float* ws;
+    double plan_makespan, plan_ideal;        // (diagnostics: tile-steps of the simulated dispatch / of a perfect balance)
+};
+#define WG_TABLE_MAGIC 0x57474754u
+extern "C" size_t rsu_wgrad_group_table_bytes(void) { return sizeof(WgGroupTable); }
+// the planner only makes plans whose slabs fit this many floats: up to 512 slabs (two per CU) of a 128 x 64 x 9 block plus a bias row,
+// times two (the slab of a concat source spans the rows of all sources of its kernel)
+extern "C" size_t rsu_wgrad_group_ws_floats(void) { return (size_t)2 * 512 * (9 * 128 * 64 + 1024) + 4096; }
+static int prep_group_job(WgPrep& w, const rsu_wgrad_job_t& j, int N, int ncu) {
+    if (j.kind == RSU_WGRAD_CONV3X3) {
+        const rsu_src_t* src = &j.src;
+        if (!src->ptr || !j.dz || !j.dw || src->C % 8 || j.Cout % 8 || j.ci_off + src->C > j.Cin_total || (j.dil != 1 && j.dil != 2)) return RSU_EINVAL;
+        if (src->oy < 0 || src->ox < 0 || src->oy + j.Ho + 2 * j.dil > src->H || src->ox + j.Wo + 2 * j.dil > src->W || j.Wo < 2) return RSU_EINVAL;
+        return prep_wgrad(w, IGW_CFG_64x64, j.dz, j.Ho, j.Wo, j.Cout, src, j.dw, j.Cin_total, j.Cout, j.ci_off, N, 9, 3, j.dil, 1, ncu, j.db, nullptr);
+    }
+    if (j.kind == RSU_WGRAD_CONVT2X2) {   // src = x [N][H][W][Cin], dz = dy [N][2H][2W][Cout]
+        const int H = j.src.H, W = j.src.W, Cin = j.src.C, Cout = j.Cout;
+        if (!j.src.ptr || !j.dz || !j.dw || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+        rsu_src_t s;
+        s.ptr = j.dz; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
+        return prep_wgrad(w, IGW_CFG_64x64, j.src.ptr, H, W, Cin, &s, j.dw, Cout, Cin, 0, N, 4, 2, 1, 2, ncu, nullptr, j.db);
+    }
+    return RSU_EINVAL;
+}
+// relative time of one pixel tile (128 pixels) of one unit, by kernel family (the 128 x 64 x 9 ping-pong kernel = 1)
+static double wg_family_cost(int family) {
+    if (family >= IGW_FAM_WGPP3 && family <= IGW_FAM_WGPP6) return 1.0;
+    if (family == IGW_FAM_WGP64_4 || family == IGW_FAM_WGP64_5) return 0.58;
+    switch (family - IGW_FAM_GENERIC) {
+        case 2 * IGW_CFG_64x64 + 1: return 0.45;    // 64 x 64 x 4 taps, generic kernel
+        case 2 * IGW_CFG_64x16: return 0.30;
+        case 2 * IGW_CFG_128x64: return 1.25;       // dilated 3x3, generic kernel
+        case 2 * IGW_CFG_128x64 + 1: return 0.62;   // 128 x 64 x 4 taps
+    }
+    return 1.0;
+}
+extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, float* ws, int N, int ncu_arg, void* host_table) {
+    if (!jobs || njobs < 1 || njobs > IGW_GROUP_MAX || !ws || !host_table || N < 1) return RSU_EINVAL;
+    const int ncu = launch_ncu(ncu_arg);
+    if (ncu < 0) return RSU_EINVAL;
+    WgGroupTable& T = *(WgGroupTable*)host_table;
+    memset(&T, 0, sizeof(T));
+    T.magic = WG_TABLE_MAGIC; T.N = N; T.ncu = ncu; T.ws = ws;
+    struct Item { WgPrep w; int family, blocks, nsplit; double cost, unit; };
+    std::array<Item, IGW_GROUP_MAX> it;
+    int n = 0;
+    double W = 0.0;
+    for (int i = 0; i < njobs; ++i) {
+        Item& a = it[n];
+        const int rc = prep_group_job(a.w, jobs[i], N, ncu);
+        if (rc != RSU_OK) return rc;
+        a.family = env_int("RSU_WG_GEN", 2) >= 2 ? igemm_wg_group_family(a.w.cfg, a.w.ntap, a.w.p) : -1;
+        if (a.family >= 0 && igemm_wg_group_lds_bytes(a.family, a.w.p) > (size_t)IGW_GROUP_LDS_BYTES - 256) a.family = -1;
+        if (a.family < 0) {   // no grouped body for this shape: a launch of its own behind the group
+            T.single[T.nsingle++] = jobs[i];
+            continue;
+        }
+        a.blocks = a.w.gx * a.w.gy;
+        a.cost = wg_family_cost(a.family);
+        W += (double)a.blocks * a.w.ntiles * a.cost;
+        ++n;
+    }
+    if (n > 0) {
+        // Units: job i is cut into blocks_i x nsplit_i units of ~ntiles_i / nsplit_i pixel tiles. The kernel runs ONE unit per workgroup and
+        // the dispatcher deals workgroups to CUs as they fall free, so the plan is a list schedule: long units first. Splitting costs a
+        // slab per unit (written and read back), so the shallow layers get units of about W / ncu / k tile-steps and the deep layers
+        // (many channel blocks, few pixels) none. k is chosen by simulating the dispatch for a few values.
+        const double slab_cost = 0.55;   // tile-steps one slab costs its launch (write + its share of the reduce), measured order
+        double best = 1e300;
+        int best_split[IGW_GROUP_MAX] = {0};
+        const double ks[5] = {1.0, 1.5, 2.0, 3.0, 4.0};
+        for (int ki = 0; ki < 5; ++ki) {
+            const double target = W / ncu / ks[ki];
+            int split[IGW_GROUP_MAX];
+            std::vector<double> units;
+            double slabs = 0.0, ws_need = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double s = (double)it[i].w.ntiles * it[i].cost / (target > 0 ? target : 1.0);
+                int ns = s < 1.4 ? 1 : (int)(s + 0.5);
+                if (ns > it[i].w.ntiles) ns = it[i].w.ntiles;
+                if (ns < 1) ns = 1;
+                split[i] = ns;
+                const double unit = (double)cdiv(it[i].w.ntiles, ns) * it[i].cost + (ns > 1 ? slab_cost : 0.0);
+                for (int u = 0; u < it[i].blocks * ns; ++u) units.push_back(unit);
+                if (ns > 1) {
+                    slabs += (double)it[i].blocks * ns;
+                    ws_need += (double)ns * (double)(it[i].w.main_elems + it[i].w.extra);
+                }
+            }
+            if (ws_need > (double)rsu_wgrad_group_ws_floats()) continue;
+            if (units.size() > IGW_UNITS_MAX) continue;
+            std::sort(units.begin(), units.end(), [](double a, double b) { return a > b; });
+            std::vector<double> cu((size_t)ncu, 0.0);   // greedy dispatch: the next unit goes to the CU that falls free first
+            for (double u : units) {
+                size_t m = 0;
+                for (size_t c = 1; c < cu.size(); ++c)
+                    if (cu[c] < cu[m]) m = c;
+                cu[m] += u;
+            }
+            double mk = 0.0;
+            for (double c : cu) mk = c > mk ? c : mk;
+            if (mk < best) {
+                best = mk;
+                for (int i = 0; i < n; ++i) best_split[i] = split[i];
+            }
+        }
+        if (best >= 1e300) return RSU_EINVAL;
+        T.plan_makespan = best;
+        T.plan_ideal = W / ncu;
+        for (int i = 0; i < n; ++i) {
+            it[i].nsplit = best_split[i];
+            it[i].unit = (double)cdiv(it[i].w.ntiles, it[i].nsplit) * it[i].cost;
+        }
+        // longest units first (stable: ties keep the caller's order)
+        std::array<int, IGW_GROUP_MAX> order;
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.begin() + n, [&](int a, int b) { return it[a].unit > it[b].unit; });
+        float* wsp = ws;
+        int rb = 0;
+        struct U { double len; unsigned code; };
+        std::vector<U> ulist;
+        for (int k = 0; k < n; ++k) {
+            Item& a = it[order[k]];
+            finish_wgrad(a.w, a.nsplit, wsp);
+            IgWgJob& J = T.g.job[k];
+            J.p = a.w.p;
+            J.gx = a.w.gx; J.gy = a.w.gy; J.gz = a.nsplit;
+            J.family = a.family;
+            for (int u = 0; u < a.blocks * a.nsplit; ++u) ulist.push_back(U{a.unit + (a.nsplit > 1 ? slab_cost : 0.0), ((unsigned)k << 24) | (unsigned)u});
+            const size_t lds = igemm_wg_group_lds_bytes(a.family, a.w.p);
+            if (lds > T.lds_bytes) T.lds_bytes = lds;
+            if (a.nsplit > 1) {
+                ReduceJob& R = T.red[T.nred++];
+                R.slab = wsp; R.out = a.w.out; R.out2 = a.w.db ? a.w.db : a.w.dbs;
+                R.slab_elems = a.w.p.slab_stride;
+                R.n2 = a.w.extra / 4; R.nsplit = a.nsplit; R.ntap = a.w.ntap;
+                R.CsOut = a.w.p.CsOut; R.cs_off = a.w.p.cs_off; R.cs_cnt = a.w.cs_cnt; R.CfOut = a.w.p.CfOut;
+                R.block_begin = rb;
+                rb += ew_reduce_job_blocks(R);
+                wsp += (size_t)a.nsplit * a.w.p.slab_stride;
+            }
+        }
+        if ((size_t)(wsp - ws) > rsu_wgrad_group_ws_floats()) return RSU_ENOMEM;
+        // deal the units to the workgroups: longest first, each to the workgroup with the least work so far (ties: lowest id), then
+        // every workgroup's list in the order it received them (long units first)
+        std::stable_sort(ulist.begin(), ulist.end(), [](const U& a, const U& b) { return a.len > b.len; });
+        const int nwg = (int)std::min<size_t>((size_t)ncu, ulist.size());
+        std::vector<double> load((size_t)nwg, 0.0);
+        std::vector<std::vector<unsigned>> mine((size_t)nwg);
+        for (const U& u : ulist) {
+            int m = 0;
+            for (int c = 1; c < nwg; ++c)
+                if (load[c] < load[m]) m = c;
+            load[m] += u.len;
+            mine[m].push_back(u.code);
+        }
+        int pos = 0;
+        for (int b = 0; b < nwg; ++b) {
+            T.g.wg_first[b] = pos;
+            for (unsigned c : mine[b]) T.g.unit[pos++] = c;
+        }
+        for (int b = nwg; b <= 256; ++b) T.g.wg_first[b] = pos;
+        T.g.njobs = n;
+        T.g.nwg = nwg;
+        T.nwg_total = nwg;
+        T.red_blocks = rb;
+        if (env_int("RSU_PLAN_DEBUG", 0)) {
+            fprintf(stderr, "[plan wg group] %d jobs, %d units on %d CUs, makespan %.1f tile-steps (ideal %.1f), %d reduce jobs, %.1f MB of slabs, %d single launches\n",
+                    n, (int)ulist.size(), ncu, best, W / ncu, T.nred, (double)(wsp - ws) * 4e-6, T.nsingle);
+            for (int k = 0; k < n; ++k)
+                fprintf(stderr, "   job %2d: family %2d blocks %3d x split %3d, %5d tiles, unit %.1f\n", k, T.g.job[k].family, T.g.job[k].gx * T.g.job[k].gy,
+                        T.g.job[k].gz, T.g.job[k].p.ntiles_total, it[order[k]].unit);
+        }
+    }
+    return RSU_OK;
+}
+extern "C" int rsu_wgrad_group_run(const void* host_table, const void* dev_table, rsu_stream_t stream) {
+    if (!host_table || !dev_table) return RSU_EINVAL;
+    const WgGroupTable& T = *(const WgGroupTable*)host_table;
+    if (T.magic != WG_TABLE_MAGIC) return RSU_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (T.g.njobs > 0) {
+        HIP_CHECK_RET(igemm_wg_group_launch((const IgWgGroupParams*)dev_table, T.nwg_total, st));
+        if (T.nred > 0)
+            HIP_CHECK_RET(ew_reduce_slabs_many((const ReduceJob*)((const char*)dev_table + offsetof(WgGroupTable, red)), T.nred, T.red_blocks, st));
+    }
+    for (int i = 0; i < T.nsingle; ++i) {   // (stream order: the group's slabs have been reduced before these reuse the workspace)
+        const rsu_wgrad_job_t& j = T.single[i];
+        int rc;
+        if (j.kind == RSU_WGRAD_CONV3X3)
+            rc = rsu_conv2d_bwd_weight(&j.src, j.dz, j.dw, j.db, T.ws, T.N, j.Ho, j.Wo, j.Cin_total, j.ci_off, j.Cout, j.dil, T.ncu, stream);
+        else
+            rc = rsu_convT2x2_bwd_weight(j.src.ptr, j.dz, j.dw, j.db, T.ws, T.N, j.src.H, j.src.W, j.src.C, j.Cout, T.ncu, stream);
+        if (rc != RSU_OK) return rc;
+    }
     return RSU_OK;
 }
 

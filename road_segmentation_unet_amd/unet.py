@@ -14,12 +14,17 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import RsuSrc, call
+from ._lib import RsuSrc, RsuWgradJob, call
 
 NUM_CHANNELS = 3  # src/constants.py:3
 NUM_LABELS = 2    # src/constants.py:4
 
 
+# RSU_WG_GROUP: how the weight gradients of a backward pass are launched (UNet._flush_wgrads). Default: one launch per layer where a
+# side stream runs them beside the backward-data launches (each kernel on half the chip: per layer they are as efficient there as a
+# group, and the fine grain keeps both streams busy to the end -- measured, profiles/r03/wg_group_schedules.txt), ONE grouped launch behind
+# the pass where everything runs on one stream (alone on the chip a layer's launch pays 75 MB of slabs and a partly filled last round)
+_WG_GROUP_TWO_STREAMS, _WG_GROUP_ONE_STREAM = "0", "all"
 _SPLIT_DEFAULT = "128,128"   # RSU_SPLIT_CHIP: CUs the main stream / each side stream plan for during the backward pass (UNet._Side)
 
 
@@ -112,6 +117,12 @@ class UNet:
         self.backward_cu_budget = None   # CUs the backward launches may plan for in total (None: the library's default)
         self._ncu = 0          # `ncu` argument of the MFMA launches issued now (0: the library's default budget)
         self._tuned = set()    # (training?, backward_cu_budget) combinations the tuning pass has run for (tune / ensure_tuned)
+        # grouped weight gradients (rsu.h rsu_wgrad_group_*): the launches of RSU_WG_GROUP consecutive levels / decoder stages of the
+        # backward pass go out as ONE launch (0: one launch per layer, as in round 2; "all": one group behind the whole pass)
+        self._wg_sizes, self._wg_group = [0], 0   # set per backward pass (_wg_policy)
+        self._wg_pending, self._wgT_pending, self._wg_levels, self._wg_event, self._wg_index = [], [], 0, None, 0
+        self._side_active = False   # a weight-gradient launch has gone to the side stream in this backward pass
+        self._wg_plans = {}
         self._side_rr = 0
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
@@ -240,6 +251,7 @@ class UNet:
                     ws.append(lib.rsu_bias_grad_ws_floats(B * S * S, s[3]))
                 if n.startswith("up_conv") and n.endswith("kernel"):
                     ws.append(lib.rsu_convT2x2_bwd_weight_ws_floats(s[3], s[2]))
+            ws.append(lib.rsu_wgrad_group_ws_floats())
             self.ws = torch.zeros(int(max(ws)) + 64, dtype=torch.float32, device=dev)
             # (one workspace per stream that launches weight gradients: their slabs are live at the same time)
             self.ws_side = [self.ws] + [torch.zeros_like(self.ws) for _ in self.wstreams[1:]]
@@ -326,6 +338,7 @@ class UNet:
 
     def _grads_ready(self, name):
         if self.on_grads is not None:  # (dist.GradBucketer waits for the weight-gradient stream itself: extra_streams)
+            self._flush_wgrads()       # queued weight gradients must be ON the side stream before the exchange may wait for it
             self.on_grads(self._slices[name][0])
 
     # Weight-gradient launches can go to a second stream: they only READ what the main stream produced (dz, activations) and
@@ -338,15 +351,23 @@ class UNet:
     # own CUs, instead of taking turns on all of them. The weight gradient of a layer is a sum over one partial result PER
     # WORKGROUP (a 295-KB slab each, written and read back by the reduce kernel): half the workgroups, half that traffic --
     # and persistent kernels on fewer CUs lose less to their last, partly filled round of tiles. "0" = both plan for every CU.
+    def _wg_policy(self):
+        """RSU_WG_GROUP for this backward pass: "n" every group holds n blocks; "a,b,c" the first group a blocks, the second b, ... (the
+        last number repeats); "all" one group behind the whole pass; "0" one launch per layer"""
+        g = os.environ.get("RSU_WG_GROUP", _WG_GROUP_TWO_STREAMS if self.wstreams else _WG_GROUP_ONE_STREAM)
+        self._wg_sizes = [10 ** 6] if g == "all" else [max(0, int(v)) for v in g.split(",")]
+        self._wg_group = self._wg_sizes[0]
+
     def _begin_split(self):
         """CU shares of the backward pass: `backward_cu_budget` (set by the data-parallel host: CUs left to RCCL's channel workgroups
         while the gradient exchange overlaps the backward pass; the forward pass keeps the whole chip) shared out between the
         streams. Every launch carries its share as its own `ncu` argument (self._ncu): no library state changes between launches."""
         self._split = None
+        self._wg_policy()
         full = self.backward_cu_budget or _lib.lib().rsu_get_cu_budget()
         spec = os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT)
         parts = None
-        if self.wstreams and spec not in ("0", ""):
+        if self.wstreams and spec not in ("0", "") and self._wg_group < 10 ** 6:   # (RSU_WG_GROUP=all: nothing runs beside backward-data)
             try:
                 parts = [int(v) for v in spec.split(",")]
             except ValueError:
@@ -358,18 +379,22 @@ class UNet:
             return
         parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
         self._split = (full, parts[0], parts[1:])
-        self._ncu = parts[0]
+        # the main stream keeps the whole budget until the first weight-gradient launch has gone to the side stream
+        self._ncu = full if self.backward_cu_budget else 0
 
     def _end_split(self):
         self._split = None
         self._ncu = 0
+        self._side_active = False
+        self._wg_index = 0
 
     class _Side:
         """`with UNet._Side(net) as side:` -- launches inside go to the next side stream (round robin) and plan for that stream's share
         of the chip; side.ws is its workspace"""
 
-        def __init__(self, net, alone=False):
+        def __init__(self, net, alone=False, after=None):
             self.net, self.ctx, self.alone = net, None, alone  # alone: nothing is left to run beside it on the main stream
+            self.after = after   # event on the main stream behind which the side stream may start (None: everything issued so far)
             self.ws = net.ws if net.training else None
             self.saved_ncu = net._ncu
 
@@ -383,8 +408,10 @@ class UNet:
             self.ws = n.ws_side[k]
             if n._split is not None:
                 n._ncu = n._split[0] if self.alone else n._split[2][k]
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(n.device))
+            ev = self.after
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(n.device))
             n.wstreams[k].wait_event(ev)
             self.ctx = torch.cuda.stream(n.wstreams[k])
             self.ctx.__enter__()
@@ -395,7 +422,11 @@ class UNet:
                 if self.ctx is not None:
                     self.ctx.__exit__(*a)
             finally:
-                self.net._ncu = self.saved_ncu   # on error paths too
+                n = self.net
+                n._ncu = self.saved_ncu   # on error paths too
+                if n._split is not None and self.ctx is not None and not n._side_active:
+                    n._side_active = True   # from here on the main stream's launches share the chip with the side stream's
+                    n._ncu = n._split[1]
 
     def _join_side(self):
         for s in self.wstreams:
@@ -478,10 +509,27 @@ class UNet:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, name, srcs_t, dz, hout, dil=1):
-        """dW (HWIO rows per source) + db of conv `name`; srcs_t = list of (tensor, window size)"""
+        """dW (HWIO rows per source) + db of conv `name`; srcs_t = list of (tensor, window size). With grouping on (RSU_WG_GROUP) the
+        launches are only queued here; _flush_wgrads sends a whole group to the side stream as one launch."""
         cout = dz.shape[3]
         cin_total = self.w[name + "/kernel"].shape[2]
         off = 0
+        if self._wg_group > 0:
+            for t, win in srcs_t:
+                db = self.g[name + "/bias"] if off == 0 else None  # BiasAddGrad rides along with the first source's launch
+                job = RsuWgradJob(_lib.WGRAD_CONV3X3, _src(t, win, win), dz.data_ptr(), self.g[name + "/kernel"].data_ptr(),
+                                  db.data_ptr() if db is not None else None, hout, hout, cin_total, off, cout, dil)
+                self._wg_pending.append((job, 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, (name, off)))
+                off += t.shape[3]
+            self._wg_event = self._record_main()   # everything these jobs read has been issued by now: the group need not wait for more
+            if name.endswith("conv2") and not (name.startswith("conv_0/") and not self.dilated):   # (the last group: flushed by the caller, which knows that nothing runs beside it)
+                # a group closes BEHIND a conv2 gradient: dz of a block's conv2 is there when the block's backward pass begins, so the
+                # group {conv1 (+ transposed conv) of the block before, conv2 of this one} can run beside ALL of this block's
+                # backward-data launches; closing it behind conv1 would make it wait for the block's first backward-data launch
+                self._wg_levels += 1
+                if self._wg_levels >= self._wg_sizes[min(self._wg_index, len(self._wg_sizes) - 1)]:
+                    self._flush_wgrads()
+            return
         with UNet._Side(self) as side:
             st = self._stream()
             for t, win in srcs_t:
@@ -491,6 +539,53 @@ class UNet:
                             _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil,
                             self._ncu, st)
                 off += t.shape[3]
+
+    def _wgradT(self, i, upin, dup, hh, nf):
+        """dK + db of up_conv_i (queued like _wgrad when grouping is on)"""
+        if self._wg_group > 0:
+            job = RsuWgradJob(_lib.WGRAD_CONVT2X2, RsuSrc(upin.data_ptr(), hh, hh, upin.shape[3], 0, 0), dup.data_ptr(),
+                              self.g["up_conv_%d/kernel" % i].data_ptr(), self.g["up_conv_%d/bias" % i].data_ptr(), 0, 0, 0, 0, nf, 1)
+            self._wgT_pending.append((job, 0.0, ("up_conv_%d" % i, upin.data_ptr())))
+            self._wg_event = self._record_main()
+            return
+        with UNet._Side(self) as side:
+            call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
+                 _ptr(side.ws), self.B, hh, hh, upin.shape[3], nf, self._ncu, self._stream())
+
+    def _record_main(self):
+        if not self.wstreams:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def _flush_wgrads(self, alone=False):
+        """Launch the queued weight gradients as grouped launches on the side stream (everything they read has been produced by launches
+        issued on the main stream before this point; _Side makes the side stream wait for them). The plan of a group -- which layers,
+        which CU share, which workspace -- is made once and kept (host table + its device copy, rsu.h rsu_wgrad_group_plan)."""
+        self._wg_levels = 0
+        self._wg_index += 1
+        for pending, tag in ((self._wg_pending, "conv3x3_bwd_weight"), (self._wgT_pending, None)):
+            while pending:
+                chunk, rest = pending[:_lib.WGRAD_GROUP_MAX], pending[_lib.WGRAD_GROUP_MAX:]
+                del pending[:]
+                pending.extend(rest)
+                with UNet._Side(self, alone=alone, after=self._wg_event) as side:
+                    key = (tuple(k for _, _, k in chunk), self._ncu, side.ws.data_ptr())
+                    plan = self._wg_plans.get(key)
+                    if plan is None:
+                        lib = _lib.lib()
+                        nb = lib.rsu_wgrad_group_table_bytes()
+                        host = ctypes.create_string_buffer(nb)
+                        arr = (RsuWgradJob * len(chunk))(*[j for j, _, _ in chunk])
+                        _lib.check(lib.rsu_wgrad_group_plan(arr, len(chunk), _ptr(side.ws), self.B, self._ncu, host), "rsu_wgrad_group_plan")
+                        devt = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+                        plan = self._wg_plans[key] = (host, devt)
+                    flops = sum(f for _, f, _ in chunk)
+                    if tag is None:
+                        call("rsu_wgrad_group_run", plan[0], _ptr(plan[1]), self._stream())
+                    else:
+                        self._timed(tag, flops, "rsu_wgrad_group_run", plan[0], _ptr(plan[1]), self._stream())
 
     def _bwd_data(self, name, dz, dx, hin, relu_src=None, accumulate=0, src_index=0, dil=1):
         """Conv2DBackpropInput towards concat source `src_index` of conv `name` (its own weight pack)"""
@@ -550,9 +645,7 @@ class UNet:
             if keep < 1.0:  # the transposed conv read the dropped tensor; (dropped > 0) = ReLU mask AND keep mask
                 upin = a["drop_%d" % i]
             hh = h // 2
-            with UNet._Side(self) as side:
-                call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
-                     _ptr(side.ws), B, hh, hh, upin.shape[3], nf, self._ncu, self._stream())
+            self._wgradT(i, upin, dup, hh, nf)
             call("rsu_convT2x2_bwd_data", _ptr(dup), _ptr(self.pk["up_conv_%d/kernel" % i, "bwd"]), _ptr(gin), _ptr(upin), float(np.float32(1.0) / np.float32(keep)), B, hh, hh,
                  upin.shape[3], nf, self._ncu, st)
             self._grads_ready("up_conv_%d/kernel" % i)  # up_conv_i, conv_{L+i} and everything created later are final
@@ -574,6 +667,9 @@ class UNet:
                 self._wgrad("conv_%d/conv1" % i, [(pin, h)], dz1, h - 2)
                 self._bwd_data("conv_%d/conv1" % i, dz1, g["pool_%d" % (i - 1)], h)
             else:
+                # the last group: nothing is left to run beside it on the main stream (unless the dilated twin of level 0 follows), so
+                # it plans for the whole chip; the level-0 conv1 gradient below is a launch of its own
+                self._flush_wgrads(alone=not (self.dilated and L > 1))
                 with UNet._Side(self, alone=not (self.dilated and L > 1)) as side:
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
                          _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._ncu, self._stream())
@@ -599,6 +695,7 @@ class UNet:
                 # (marking it ready launched nothing, and the largest block waited for level L-2)
                 first_name = ("conv_dilut_%d/atrous_conv1/kernel" if (self.dilated and i < L - 1) else "conv_%d/conv1/kernel") % i
                 self._grads_ready(first_name)
+        self._flush_wgrads(alone=True)
         self._join_side()
 
     def tune(self, training=None):

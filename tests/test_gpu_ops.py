@@ -216,6 +216,78 @@ def test_conv2d_bwd_weight_cropped_sources():
     hu.assert_f32_close(hu.host(dw), U.conv2d_bwd_weight(cat, dz)[0], "bwd_weight 2 cropped sources")
 
 
+@pytest.mark.parametrize("ncu", [0, 64])
+def test_wgrad_group_equals_single_launches(ncu):
+    """rsu_wgrad_group_plan / _run: several layers' weight gradients in ONE launch (every kernel family: the 128x64 ping-pong shape at
+    two strip widths, the 64-channel ping-pong shape, a dilated conv and a concat source on the generic kernel, a transposed conv)
+    against the oracle and against the single launches (equal up to the summation order of the pixel splits)"""
+    from road_segmentation_unet_amd._lib import RsuWgradJob
+    rng = np.random.RandomState(77 + ncu)
+    N = 2
+    # (kind, H, W, Cin_total, ci_off, src C, Cout, dil)
+    specs = [(0, 38, 38, 128, 0, 128, 128, 1), (0, 70, 52, 64, 0, 64, 64, 1), (0, 20, 20, 256, 0, 256, 512, 1), (0, 44, 44, 64, 0, 64, 128, 2),
+             (0, 30, 30, 96, 32, 64, 192, 1), (1, 11, 13, 128, 0, 128, 64, 1), (0, 150, 26, 128, 0, 128, 128, 1), (0, 33, 47, 64, 0, 64, 64, 2)]
+    jobs, keep, checks = [], [], []
+    for kind, H, W, cin_t, off, csrc, cout, dil in specs:
+        if kind == 0:
+            Ho, Wo = H - 2 * dil, W - 2 * dil
+            x = hu.q(_rand(rng, N, H, W, csrc))
+            dz = hu.q(_rand(rng, N, Ho, Wo, cout, scale=0.1))
+            xd, dzd = hu.dev_bf16(x), hu.dev_bf16(dz)
+            dw = torch.zeros((3, 3, cin_t, cout), dtype=torch.float32, device=hu.DEV)
+            db = torch.full((cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+            jobs.append(RsuWgradJob(0, hu.src_of(xd, H, W), dzd.data_ptr(), dw.data_ptr(), db.data_ptr(), Ho, Wo, cin_t, off, cout, dil))
+            rdw, rdb = U.conv2d_bwd_weight(x, dz, dil=dil)
+            checks.append((dw, db, rdw, rdb, off, csrc, ("conv", xd, dzd, H, W, Ho, Wo, cin_t, off, cout, dil)))
+            keep += [xd, dzd, dw, db]
+        else:
+            x = hu.q(_rand(rng, N, H, W, cin_t))
+            dy = hu.q(_rand(rng, N, 2 * H, 2 * W, cout, scale=0.1))
+            K = _rand(rng, 2, 2, cout, cin_t, scale=0.1)
+            xd, dyd = hu.dev_bf16(x), hu.dev_bf16(dy)
+            dK = torch.full((2, 2, cout, cin_t), float("nan"), dtype=torch.float32, device=hu.DEV)
+            db = torch.full((cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+            jobs.append(RsuWgradJob(1, RsuSrc(xd.data_ptr(), H, W, cin_t, 0, 0), dyd.data_ptr(), dK.data_ptr(), db.data_ptr(), 0, 0, 0, 0, cout, 1))
+            _, rdK, rdb = U.convT_bwd(x, K, dy, need_dx=False)
+            checks.append((dK, db, rdK, rdb, None, None, ("convT", xd, dyd, H, W, cin_t, cout)))
+            keep += [xd, dyd, dK, db]
+    nws = lib().rsu_wgrad_group_ws_floats()
+    ws = torch.zeros(nws + 4096, dtype=torch.float32, device=hu.DEV)
+    ws[nws:] = 12345.0
+    nb = lib().rsu_wgrad_group_table_bytes()
+    host = ctypes.create_string_buffer(nb)
+    arr = (RsuWgradJob * len(jobs))(*jobs)
+    assert lib().rsu_wgrad_group_plan(arr, len(jobs), hu.ptr(ws), N, ncu, host) == 0
+    devt = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(hu.DEV)
+    for rep in range(2):   # a second run gives the same bits (fixed summation order)
+        call("rsu_wgrad_group_run", host, hu.ptr(devt), hu.stream())
+        got = [(hu.host(dw).copy(), hu.host(db).copy()) for dw, db, *_ in checks]
+        if rep == 0:
+            first = got
+        else:
+            for (a, b), (c, d) in zip(first, got):
+                np.testing.assert_array_equal(a, c)
+                np.testing.assert_array_equal(b, d)
+    assert bool((ws[nws:] == 12345.0).all()), "workspace overrun"
+    ws1 = torch.zeros(max(lib().rsu_conv2d_bwd_weight_ws_floats(256, 256, 512), lib().rsu_convT2x2_bwd_weight_ws_floats(128, 64)) + 64,
+                      dtype=torch.float32, device=hu.DEV)
+    for (gdw, gdb), (dw, db, rdw, rdb, off, csrc, single) in zip(first, checks):
+        if single[0] == "conv":
+            hu.assert_f32_close(gdw[:, :, off:off + csrc], rdw, "group conv wgrad")
+            assert not gdw[:, :, :off].any() and not gdw[:, :, off + csrc:].any(), "rows outside the source were written"
+            hu.assert_f32_close(gdb, rdb, "group conv bias grad")
+            _, xd, dzd, H, W, Ho, Wo, cin_t, off_, cout, dil = single
+            dw1 = torch.zeros_like(dw)
+            db1 = torch.zeros_like(db)
+            s = hu.src_of(xd, H, W)
+            call("rsu_conv2d_bwd_weight", ctypes.byref(s), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(db1), hu.ptr(ws1), N, Ho, Wo, cin_t, off_, cout, dil, 0, hu.stream())
+            scale = float(np.abs(rdw).max())
+            assert float(np.abs(hu.host(dw1) - gdw).max()) <= 2e-5 * scale
+        else:
+            hu.assert_f32_close(gdw, rdw, "group convT wgrad")
+            hu.assert_f32_close(gdb, rdb, "group convT bias grad")
+
+
 # ------------------------------------------------------------------------------------------- first layer
 @pytest.mark.parametrize("dil,keep", [(1, 1.0), (2, 1.0), (1, 0.8)])
 def test_color_adjust_and_first_conv(dil, keep):

@@ -50,13 +50,18 @@ def test_short_training_runs_are_bit_identical():
 
 
 def test_two_stream_schedule_does_not_change_the_numbers(monkeypatch):
-    """The weight-gradient launches run on side streams by default; the same steps on one stream must give the same bits (with
-    every launch planned for the whole chip: RSU_SPLIT_CHIP=0), and the same numbers to summation order with the chip shared out
-    between the streams (fewer, longer partial sums per weight gradient)."""
+    """The weight-gradient launches run on side streams by default; the same launches on one stream must give the same bits (with
+    every launch planned for the whole chip: RSU_SPLIT_CHIP=0, one launch per layer: RSU_WG_GROUP=0), and the same numbers to
+    summation order with the chip shared out between the streams (fewer, longer partial sums per weight gradient) or with the weight
+    gradients grouped into few launches (RSU_WG_GROUP: the default on one stream is ONE group behind the pass)."""
     from road_segmentation_unet_amd.unet import UNet
 
-    def run(single_stream, split="0"):
+    def run(single_stream, split="0", group="0"):
         monkeypatch.setenv("RSU_SPLIT_CHIP", split)
+        if group is None:
+            monkeypatch.delenv("RSU_WG_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("RSU_WG_GROUP", group)
         m = UNet(4, 32, True, 2, 204, seed=11, training=True)
         if single_stream:
             m.wstream, m.wstreams = None, []
@@ -75,6 +80,10 @@ def test_two_stream_schedule_does_not_change_the_numbers(monkeypatch):
     for split in ("128,128", "128,64,64"):
         c = run(False, split)
         assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), split
+    for single, split, group in ((True, "0", None), (False, "128,128", "1"), (False, "128,128", "2,3"), (True, "0", "all")):
+        c = run(single, split, group)
+        assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), (single, split, group)
+        assert torch.equal(c, run(single, split, group)), "a grouped schedule must repeat bit for bit"
 
 
 def test_measured_tile_shapes_do_not_change_the_numbers():
