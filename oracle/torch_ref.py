@@ -48,20 +48,31 @@ def torch_unet(params, X, L, root, dilated, dtype=torch.float64):
     return conv(net, "weight_output", relu=False), P
 
 
-def timed_train_step_fp32(params, X, labels, L, root, dilated, lr=0.01, momentum=0.9, threads=None):
-    """one forward + loss + backward + Momentum update in float32 on the CPU; returns (seconds, loss)"""
+def timed_train_step_fp32(params, X, labels, L, root, dilated, lr=0.01, momentum=0.9, threads=None, repeats=3):
+    """forward + loss + backward + Momentum update in float32 on the CPU. One untimed warm-up step (oneDNN primitive creation,
+    thread-pool start, first-touch of the buffers), then `repeats` timed steps on parameter tensors created OUTSIDE the timed
+    region; returns (best seconds, loss of the last step)"""
     if threads:
         torch.set_num_threads(int(threads))
     acc = {k: torch.zeros(np.asarray(v).shape, dtype=torch.float32) for k, v in params.items()}
-    t0 = time.time()
-    logits, P = torch_unet(params, X, L, root, dilated, dtype=torch.float32)
-    lt = logits.permute(0, 2, 3, 1).reshape(-1, 2)
-    loss = F.cross_entropy(lt, torch.from_numpy(np.asarray(labels)).reshape(-1))
-    loss.backward()
-    with torch.no_grad():
-        for k, p in P.items():
-            if p.grad is None:
-                continue
-            acc[k].mul_(momentum).add_(p.grad)
-            p.sub_(lr * acc[k])
-    return time.time() - t0, float(loss)
+    cur = {k: np.asarray(v, dtype=np.float32).copy() for k, v in params.items()}
+    lab = torch.from_numpy(np.asarray(labels)).reshape(-1)
+    best, loss_v = float("inf"), 0.0
+    for it in range(repeats + 1):
+        logits, P = torch_unet(cur, X, L, root, dilated, dtype=torch.float32)   # (leaf creation: outside the timed region below)
+        t0 = time.time()
+        logits, P = torch_unet(cur, X, L, root, dilated, dtype=torch.float32)
+        lt = logits.permute(0, 2, 3, 1).reshape(-1, 2)
+        loss = F.cross_entropy(lt, lab)
+        loss.backward()
+        with torch.no_grad():
+            for k, p in P.items():
+                if p.grad is None:
+                    continue
+                acc[k].mul_(momentum).add_(p.grad)
+                p.sub_(lr * acc[k])
+        dt = time.time() - t0
+        if it > 0:
+            best = min(best, dt)
+        loss_v = float(loss)
+    return best, loss_v

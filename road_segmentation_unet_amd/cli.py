@@ -86,19 +86,22 @@ def main(argv=None):
             model.save(i)
 
     if opts.eval_train:
+        # tf_aerial_images.py:432-445: predict the training images and dump five picture sets next to each other (file names as the
+        # reference writes them, its "eval_orror" included, so that its downstream scripts keep finding them)
         print("Evaluate Test")
         eval_images, eval_groundtruth = hostio.load_train_data(opts.train_data_dir)
-        pred_masks = model.predict_batchwise(eval_images, opts.pred_batch_size)
+        probabilities = model.predict_batchwise(eval_images, opts.pred_batch_size)
         if rank == 0:
-            pred_labels = ((pred_masks > 0.5) * 1).squeeze(-1)
-            pred_overlays = hostio.overlays(eval_images, pred_masks, fade=0.5)
-            overlapped = hostio.overlap_pred_true(pred_labels, eval_groundtruth)
-            error = hostio.overlapp_error(pred_labels, eval_groundtruth)
-            hostio.save_all(pred_labels, opts.eval_data_dir, "eval_binary_pred_{:03d}.png", greyscale=True)
-            hostio.save_all(pred_masks, opts.eval_data_dir, "eval_probability_pred_{:03d}.png", greyscale=True)
-            hostio.save_all(pred_overlays, opts.eval_data_dir, "eval_overlays_pred_{:03d}.png")
-            hostio.save_all(overlapped, opts.eval_data_dir, "eval_confusion_{:03d}.png")
-            hostio.save_all(error, opts.eval_data_dir, "eval_orror_{:03d}.png", greyscale=True)
+            binary = ((probabilities > 0.5) * 1).squeeze(-1)
+            dumps = (
+                ("eval_binary_pred_{:03d}.png", binary, True),
+                ("eval_probability_pred_{:03d}.png", probabilities, True),
+                ("eval_overlays_pred_{:03d}.png", hostio.overlays(eval_images, probabilities, fade=0.5), False),
+                ("eval_confusion_{:03d}.png", hostio.overlap_pred_true(binary, eval_groundtruth), False),
+                ("eval_orror_{:03d}.png", hostio.overlapp_error(binary, eval_groundtruth), True),
+            )
+            for pattern, pictures, grey in dumps:
+                hostio.save_all(pictures, opts.eval_data_dir, pattern, greyscale=grey)
 
     if opts.eval_data_dir and not opts.eval_train:
         print("Running inference on eval data {}".format(opts.eval_data_dir))

@@ -121,22 +121,24 @@ def save_submission_csv(masks, path, patch_size=IMG_PATCH_SIZE):
 
 
 def overlays(imgs, masks, fade=0.95):
-    """images.py:102-128: the masks in red over the images, alpha = mask * fade (PIL alpha_composite); uint8 [n, W, H, 4]"""
+    """Road masks painted in red over the aerial images (the reference's images.overlays, images.py:102-128): per image one
+    PIL alpha-composite of an RGBA layer (red, alpha = 255 * mask * fade, truncated to uint8) onto the RGB image made opaque.
+    imgs [n, H, W, 3] float in [0, 1], masks [n, H, W(, 1)] -> uint8 [n, H, W, 4]."""
     from PIL import Image
-    imgs, masks = np.asarray(imgs), np.asarray(masks)
-    num_images, im_height, im_width, num_channel = imgs.shape
-    assert num_channel == 3, 'Predict image should be colored'
-    imgs8 = img_float_to_uint8(imgs)
-    masks8 = img_float_to_uint8(masks.squeeze())
-    masks_red = np.zeros((num_images, im_height, im_width, 4), dtype=np.uint8)
-    masks_red[:, :, :, 0] = 255
-    masks_red[:, :, :, 3] = masks8 * fade
-    results = np.zeros((num_images, im_width, im_height, 4), dtype=np.uint8)
-    for i in range(num_images):
-        x = Image.fromarray(imgs8[i]).convert('RGBA')
-        y = Image.fromarray(masks_red[i])
-        results[i] = np.array(Image.alpha_composite(x, y))
-    return results
+    pictures = img_float_to_uint8(np.asarray(imgs))
+    if pictures.ndim != 4 or pictures.shape[-1] != 3:
+        raise AssertionError('Predict image should be colored')
+    n, height, width = pictures.shape[:3]
+    alpha = (img_float_to_uint8(np.asarray(masks).reshape(n, height, width)) * fade).astype(np.uint8)
+
+    def painted(k):
+        layer = np.zeros((height, width, 4), dtype=np.uint8)
+        layer[..., 0] = 255
+        layer[..., 3] = alpha[k]
+        base = Image.fromarray(pictures[k]).convert("RGBA")
+        return np.asarray(Image.alpha_composite(base, Image.fromarray(layer)))
+
+    return np.stack([painted(k) for k in range(n)]) if n else np.zeros((0, height, width, 4), dtype=np.uint8)
 
 
 def overlap_pred_true(pred, true):

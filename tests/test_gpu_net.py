@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import unet_oracle as U  # noqa: E402
 from road_segmentation_unet_amd.unet import UNet, forward, input_size_needed  # noqa: E402
+from tests.parity_record import record  # noqa: E402
 
 CASES = [
     # L, root, P, B, dilated
@@ -184,6 +185,9 @@ def test_linearity_property_full_size_layer():
 
 # ------------------------------------------------------------------------------------------- BASELINE config 2 at full size
 C2 = (5, 64, 388)  # num_layers, root_size, patch_size (input 572)
+# stated tolerances of the full-size comparisons (measured figures: profiles/r03/parity.json)
+C2_FWD_EMU_MAX, C2_FWD_EMU_MEAN, C2_FWD_F32_MAX = 4e-3, 1e-3, 3e-2
+C2_GRAD_REL_MAX = 2e-2       # worst relative Frobenius error of a gradient tensor against the bf16-emulating oracle
 
 
 def test_c2_full_size_forward_matches_oracle():
@@ -201,11 +205,14 @@ def test_c2_full_size_forward_matches_oracle():
     d_emu, d_f32, noise = np.abs(prob - emu), np.abs(prob - f32), np.abs(emu - f32)
     print("c2 forward: max|hip-emu| %.2e mean %.2e | max|hip-f32| %.2e | oracle bf16-vs-f32 max %.2e mean %.2e" %
           (d_emu.max(), d_emu.mean(), d_f32.max(), noise.max(), noise.mean()))
-    # two correct bf16 evaluations differ by rounding-boundary flips (fp32 summation order): a fraction of the oracles' own
-    # bf16-vs-f32 distance, which grows with depth and width (150 k pixels, 23 layers, up to 1024 channels here)
-    assert d_emu.max() <= max(4e-3, 0.6 * noise.max()), (float(d_emu.max()), float(noise.max()))
-    assert d_emu.mean() <= 1e-3
-    assert d_f32.max() <= 3e-2, float(d_f32.max())
+    record("c2_forward_full_size", d_emu_max=d_emu.max(), d_emu_mean=d_emu.mean(), d_f32_max=d_f32.max(), d_f32_mean=d_f32.mean(),
+           oracle_bf16_vs_f32_max=noise.max(), oracle_bf16_vs_f32_mean=noise.mean())
+    # FIXED tolerances (profiles/r03/parity.json holds the measured figures they were set from, about 2x above them): two correct
+    # bf16 evaluations differ by rounding-boundary flips (fp32 summation order) -- a fraction of the oracles' own bf16-vs-f32
+    # distance at this depth (23 layers, up to 1024 channels, 150 k pixels)
+    assert d_emu.max() <= C2_FWD_EMU_MAX, float(d_emu.max())
+    assert d_emu.mean() <= C2_FWD_EMU_MEAN, float(d_emu.mean())
+    assert d_f32.max() <= C2_FWD_F32_MAX, float(d_f32.max())
 
 
 def test_c2_full_size_step_properties():
@@ -250,5 +257,12 @@ def test_c2_full_size_gradients_match_oracle():
     f32 = U.loss_and_grads(params, X, labels, L, root, False, emulate_bf16=False)
     noise = _rel_errs(emu[2], f32[2])
     assert abs(loss - emu[0]) <= 2e-4 * abs(emu[0]), (loss, emu[0])
-    worst = _check(loss, prob, grads, emu, 1e-2, 2e-3, 2e-2, "c2 full size vs bf16-emulating oracle", noise, 1.0)
-    print("c2 full size: worst gradient rel err %s %.2e" % worst)
+    errs = _rel_errs(grads, emu[2])
+    wn = max(errs, key=errs.get)
+    nn = max(noise, key=noise.get)
+    record("c2_gradients_full_size", loss_hip=loss, loss_emu=emu[0], loss_f32=f32[0], worst_grad_rel_err=errs[wn], worst_grad_tensor=wn,
+           oracle_bf16_vs_f32_worst_rel=noise[nn], oracle_bf16_vs_f32_worst_tensor=nn, prob_d_emu_max=float(np.abs(prob - emu[1]).max()))
+    print("c2 full size: worst gradient rel err %s %.2e (oracle bf16-vs-f32: %s %.2e)" % (wn, errs[wn], nn, noise[nn]))
+    for n, e in errs.items():
+        assert e <= C2_GRAD_REL_MAX, (n, e)
+    assert float(np.abs(prob - emu[1]).max()) <= C2_FWD_EMU_MAX

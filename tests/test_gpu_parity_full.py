@@ -20,6 +20,8 @@ from oracle import tiler_oracle as T  # noqa: E402
 from oracle import unet_oracle as U  # noqa: E402
 from road_segmentation_unet_amd.model import ConvolutionalModel, Options, pixel_f1  # noqa: E402
 from road_segmentation_unet_amd.unet import UNet  # noqa: E402
+from tests import hiputil as hu  # noqa: E402
+from tests.parity_record import record  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -96,7 +98,117 @@ def test_config3_full_size_dilated_forward_matches_oracle():
     emu = U.predict_probs(params, x, L, root, True, emulate_bf16=True)
     assert hip.shape == emu.shape == (1, P, P)
     assert np.isfinite(hip).all()
+    record("c3_forward_full_size", d_emu_max=float(np.abs(hip - emu).max()), d_emu_mean=float(np.abs(hip - emu).mean()))
     assert np.abs(hip - emu).max() <= 4e-3, float(np.abs(hip - emu).max())
+
+
+def test_config3_full_size_dilated_backward_layers_match_oracle():
+    """config 3 (L=6, root 64, dilated, 764 -> 388) BACKWARD at full size. A whole-net oracle backward would take the host hours; the
+    largest dilated and concat layers are checked one by one instead, each against the oracle's layer operator on the very tensors the
+    HIP pass left in its buffers (activations and incoming gradients, bf16): weight gradient + bias gradient, and the backward-data
+    launch where its output buffer has a single writer. Covers dil = 2 backward-data / weight-gradient launches at 760-px geometry, the
+    3 x 1024-channel concat of conv_6/conv1 and the 3 x 64-channel one of conv_10/conv1."""
+    L, root, P = 6, 64, 388
+    S = U.input_size_needed(P, L)
+    rng = np.random.RandomState(61)
+    x = rng.rand(1, S, S, 3).astype(np.float32)
+    labels = (rng.rand(1, P, P) < 0.2).astype(np.int64)
+    params = U.init_params(L, root, True, seed=62, bias_scale=0.02)
+    net = UNet(L, root, True, 1, P, params=params, training=True)
+    net.x.copy_(torch.from_numpy(x))
+    net.labels.copy_(torch.from_numpy(labels))
+    net.forward_device()
+    net.backward_device(1.0 / (P * P))
+    torch.cuda.synchronize()
+
+    def act(k):
+        return net.act[k].float().cpu().numpy()
+
+    def grd(k):
+        return net.grad[k].float().cpu().numpy()
+
+    worst = {}
+
+    def check_w(name, xin, dz, dil):
+        rdw, rdb = U.conv2d_bwd_weight(xin, dz, dil=dil)
+        gw, gb = net.g[name + "/kernel"].cpu().numpy(), net.g[name + "/bias"].cpu().numpy()
+        hu.assert_f32_close(gw, rdw, name + " weight gradient", rtol=2e-4, atol_scale=2e-5)
+        hu.assert_f32_close(gb, rdb, name + " bias gradient", rtol=2e-4, atol_scale=2e-5)
+        worst[name + "/wgrad_rel"] = float(np.linalg.norm(gw - rdw) / np.linalg.norm(rdw))
+
+    def check_dx(name, dz, w, in_hw, dil, got, mask=None, what=""):
+        ref = U.conv2d_bwd_data(dz, hu.q(w), in_hw, dil=dil)
+        if mask is not None:
+            ref = U.relu_bwd(mask, ref)
+        hu.assert_bf16_close(got, ref, name + " backward-data" + what)
+        worst[name + "/bwd_data_rel" + what] = float(np.linalg.norm(got - hu.q(ref)) / max(np.linalg.norm(ref), 1e-30))
+
+    # conv_dilut_0/atrous_conv2: 64 -> 64, dilation 2, 760 -> 756 px (the largest dilated launch)
+    d1, dzd2 = act("d1_0"), grd("d2_0")
+    check_w("conv_dilut_0/atrous_conv2", d1, dzd2, 2)
+    check_dx("conv_dilut_0/atrous_conv2", dzd2, params["conv_dilut_0/atrous_conv2/kernel"], d1.shape[1:3], 2, grd("d1_0"), mask=d1)
+    # conv_dilut_1/atrous_conv1: 64 -> 128, dilation 2 on the pooled level-0 tensor (its backward-data ACCUMULATES into the pool gradient
+    # beside conv_1/conv1's: weight gradient only), and atrous_conv2 of the same level with its masked backward-data
+    check_w("conv_dilut_1/atrous_conv1", act("pool_0"), grd("d1_1"), 2)
+    d1, dzd2 = act("d1_1"), grd("d2_1")
+    check_w("conv_dilut_1/atrous_conv2", d1, dzd2, 2)
+    check_dx("conv_dilut_1/atrous_conv2", dzd2, params["conv_dilut_1/atrous_conv2/kernel"], d1.shape[1:3], 2, grd("d1_1"), mask=d1)
+    # conv_dilut_4/atrous_conv2: 1024 -> 1024, dilation 2, the deepest live dilated pair
+    d1, dzd2 = act("d1_4"), grd("d2_4")
+    check_w("conv_dilut_4/atrous_conv2", d1, dzd2, 2)
+    check_dx("conv_dilut_4/atrous_conv2", dzd2, params["conv_dilut_4/atrous_conv2/kernel"], d1.shape[1:3], 2, grd("d1_4"), mask=d1)
+    # conv_6/conv1: concat [skip 1024, dilated skip 1024, up 1024] -> 1024 at 32 px (3072 input channels)
+    h = net.act["up_0"].shape[1]
+    cat = np.concatenate([U.center_crop(act("c2_4"), h, h), U.center_crop(act("d2_4"), h, h), act("up_0")], axis=3)
+    dz1 = grd("c1_6")
+    check_w("conv_6/conv1", cat, dz1, 1)
+    w6 = params["conv_6/conv1/kernel"]
+    check_dx("conv_6/conv1", dz1, w6[:, :, 2048:3072, :], (h, h), 1, grd("up_0"), what=" (up source)")
+    check_dx("conv_6/conv1", dz1, w6[:, :, 1024:2048, :], (h, h), 1, grd("skipd_0"), what=" (dilated skip source)")
+    # conv_10/conv1: the last decoder stage, concat [64, 64, 64] -> 64 at 392 px
+    h = net.act["up_4"].shape[1]
+    cat = np.concatenate([U.center_crop(act("c2_0"), h, h), U.center_crop(act("d2_0"), h, h), act("up_4")], axis=3)
+    dz1 = grd("c1_10")
+    check_w("conv_10/conv1", cat, dz1, 1)
+    check_dx("conv_10/conv1", dz1, params["conv_10/conv1/kernel"][:, :, 128:192, :], (h, h), 1, grd("up_4"), what=" (up source)")
+    record("c3_backward_layers_full_size", **worst)
+    print("c3 backward, layer by layer at full size:", {k: "%.2e" % v for k, v in worst.items()})
+
+
+def test_real_388_patches_pixel_f1_within_1e3_of_the_float32_oracle():
+    """The north_star's F1 claim on 388-px patches: the 16 held-out 388-patches (4 real 400-px images of the reference's training set,
+    stride 12: 2.4 M pixels) through an L=5, root=16 U-Net trained on the other 96 images (tests/golden/real388_trained_params.npz,
+    written by tests/golden/make_trained_params_388.py on the GPU): pixel-F1 of the HIP path within 1e-3 of the float32 oracle with
+    the same weights, and the probabilities within the stated bf16 tolerance of the rounding-emulating oracle."""
+    z = np.load(os.path.join(HERE, "golden", "real388_heldout.npz"))
+    pz = np.load(os.path.join(HERE, "golden", "real388_trained_params.npz"))
+    params = {k.replace("__", "/"): pz[k] for k in pz.files}
+    L, root, P, S = int(z["L"]), int(z["root"]), int(z["P"]), int(z["S"])
+    x = z["x"].astype(np.float32) / 255.0
+    y = (z["y"].astype(np.float32) / 255.0 >= 0.5) * 1.0
+    off = (S - P) // 2
+    xs, ys = [], []
+    for i in range(x.shape[0]):
+        xp = np.pad(x[i], ((off, off), (off, off), (0, 0)), mode="symmetric")
+        for ox in range(0, x.shape[1] - P + 1, 12):
+            for oy in range(0, x.shape[1] - P + 1, 12):
+                xs.append(xp[oy:oy + S, ox:ox + S])
+                ys.append(y[i][oy:oy + P, ox:ox + P])
+    xs, ys = np.stack(xs), np.stack(ys)
+    assert xs.shape[0] >= 4 and ys.size >= 600000
+    B = 4
+    net = UNet(L, root, False, B, P, params=params, training=False)
+    hip = _predict_hip(net, xs, B)
+    ref = U.predict_probs(params, xs, L, root, False)
+    emu = U.predict_probs(params, xs, L, root, False, emulate_bf16=True)
+    f_hip, f_ref, f_emu = pixel_f1(hip, ys), pixel_f1(ref, ys), pixel_f1(emu, ys)
+    record("real_388_patches_f1", f1_hip=f_hip, f1_f32_oracle=f_ref, f1_bf16_oracle=f_emu, pixels=ys.size,
+           d_emu_max=float(np.abs(hip - emu).max()), d_f32_max=float(np.abs(hip - ref).max()))
+    print("pixel-F1 on %d held-out 388-patches (%d pixels): hip %.5f  fp32 oracle %.5f  bf16-emulating oracle %.5f" %
+          (xs.shape[0], ys.size, f_hip, f_ref, f_emu))
+    assert f_ref >= 0.8, f_ref          # a network that actually segments roads
+    assert np.abs(hip - emu).max() <= 4e-3
+    assert abs(f_hip - f_ref) <= 1e-3, (f_hip, f_ref)
 
 
 def test_config4_share_full_size_training_step_properties():
