@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Achieved HBM GB/s of the bandwidth-bound kernels of the config-2 step: algorithmic bytes per step (each tensor counted once,
 SURVEY section 8d) / the kernel's time per step from a rocprofv3 kernel-stats csv (tools/gpu_bench_profile.sh).
-usage: python tools/hbm_kernels_report.py profiles/r01/g_kernel_stats.csv [steps_in_profile=15] > profiles/r01/hbm_kernels.md"""
+usage: python tools/hbm_kernels_report.py profiles/rNN/kernel_stats.csv [steps_in_profile] > profiles/rNN/hbm_kernels.md"""
 import csv
 import sys
 
@@ -19,8 +19,9 @@ n_pool_in = sum(pool_in)
 n_param = 31031822
 npix_out, npix_in = B * P * P, B * S * S
 alg = {  # kernel-name prefix -> (what, bytes per step)
-    "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout): 2 B read + 0.5 B written per input element", 2.5 * n_pool_in),
-    "_Z20k_pool_skip_relu_bwd": ("pool bwd + skip-gradient add + ReLU mask: 5.25 B per input element", 5.25 * n_pool_in),
+    "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout) + code byte: 2 B read + 0.5 B + 0.25 B written per input element", 2.75 * n_pool_in),
+    "_Z20k_pool_skip_relu_bwd": ("pool bwd + skip-gradient add + ReLU mask from the code bytes: 0.25 B code + 0.5 B dpool + ~1 B dskip (the "
+                                 "cropped window) read, 2 B dz written per input element", 3.8 * n_pool_in),
     "_Z10k_momentum": ("Momentum step: w, a, g read, w, a written (20 B per parameter)", 20.0 * n_param),
     "_Z11k_pack_many": ("f32 -> bf16 MFMA fragment order, forward + backward pack (4 B read once per pack + 2 B written)", 12.0 * n_param),
     "_Z6k_head": ("1x1 head + softmax + CE + gradients: 128 B read + 128 B written per output pixel", 256.0 * npix_out),

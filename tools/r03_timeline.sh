@@ -18,13 +18,13 @@ cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else cols[0])
 rows = cur.execute(f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
 # steps are delimited by k_momentum; take the step in front of the timed region's end: the 6th from the end is inside the timed loop
-mom = [i for i, r in enumerate(rows) if "k_momentum" in r[0]]
+mom = [i for i, r in enumerate(rows) if "k_color_adjust" in r[0] and "bwd" not in r[0]]   # a step begins with the colour adjust of its forward pass
 # the timed region holds 6 steps; the instrumented pass behind it holds 1 + 3 more: pick the 3rd timed step
 i0, i1 = mom[-8], mom[-7]
-seg = rows[i0 + 1:i1 + 1]
+seg = rows[i0:i1]
 t0 = seg[0][1]
 def short(n):
-    for k in ("igemm_wg_group", "igemm_wgpp", "igemm_wgp64", "igemm_wgrad", "igemm_pp", "igemm_fwd2", "igemm_ct", "k_reduce_slabs_many", "k_reduce_slabs", "k_pool_skip", "k_maxpool", "k_head", "k_momentum", "k_pack", "k_color"):
+    for k in ("igemm_wg_group", "igemm_wgpp", "igemm_wgp64", "igemm_wgrad", "igemm_pp", "igemm_fwd2", "igemm_ct", "k_reduce_slabs_many", "k_reduce_slabs", "k_pool_skip", "k_maxpool", "k_head", "k_momentum", "k_pack", "k_color_adjust_bwd", "k_color_adjust", "k_scatter"):
         if k in n: return k
     return n[:30]
 with open("$OUT/timeline_g$G.txt", "w") as f:
