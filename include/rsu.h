@@ -261,6 +261,22 @@ int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db,
 int rsu_momentum_step(float* w, float* acc, const float* g, float lr, float mu, float gscale, long n,
                       rsu_stream_t stream);
 
+/* The Momentum step of EVERY live variable and the re-pack of the MFMA copies in ONE launch (new): rsu_momentum_step moves 20 B per
+ * parameter and the batched re-pack reads every conv kernel twice more; this pass reads w, acc, g once, writes w, acc and both packed
+ * layouts: 24 B per weight. Same arithmetic per element as rsu_momentum_step, same packed bits as rsu_pack_*. Usage (the pattern of
+ * rsu_pack_table_*): one table entry per variable -- rsu_update_table_add for a conv / transposed-conv kernel with its packed buffers
+ * (kind RSU_PACK_CONV_FWD: packed_fwd + one backward-data pack per concat source in packed_bwd[0..nseg), or packed_bwd = NULL for a
+ * forward-only net; RSU_PACK_CONVT_FWD: packed_fwd (four matrices) + packed_bwd[0]; RSU_PACK_CONV_FIRST: packed_fwd only),
+ * rsu_update_table_add_plain for everything no MFMA kernel reads (biases, colour adjust, the 1x1 head; w / acc / g 16-byte aligned) --
+ * then rsu_update_table_finish, copy the table to the device once, and rsu_update_table_run after every backward pass. */
+size_t rsu_update_table_entry_bytes(void);
+int rsu_update_table_add_plain(void* host_table, int index, float* w, float* acc, const float* g, long n);
+int rsu_update_table_add(void* host_table, int index, int kind, float* w, float* acc, const float* g, void* packed_fwd,
+                         void* const* packed_bwd, int Cin_total, int Cout, const int* seg_c, int nseg);
+int rsu_update_table_finish(void* host_table, int nentries, int* total_blocks);
+int rsu_update_table_run(const void* dev_table, int nentries, int total_blocks, float lr, float mu, float gscale,
+                         rsu_stream_t stream);
+
 /* ---- patch / stride tiler (src/images.py) -------------------------------------------------- */
 /* images.py:269-281 mirror_border + :35-85 extract_patches fused, on device: tile t (x-outer,
  * y-inner order, images.py:76-77) of image n is the [S][S] window of the symmetric-padded image at

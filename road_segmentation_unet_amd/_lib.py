@@ -89,6 +89,11 @@ SIGNATURES = {
     "rsu_convT2x2_bwd_weight_ws_floats": (_sz, [_i, _i]),
     "rsu_convT2x2_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_momentum_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _l, _vp]),
+    "rsu_update_table_entry_bytes": (_sz, []),
+    "rsu_update_table_add_plain": (_i, [_vp, _i, _vp, _vp, _vp, _l]),
+    "rsu_update_table_add": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _i, _i, _PI, _i]),
+    "rsu_update_table_finish": (_i, [_vp, _i, _PI]),
+    "rsu_update_table_run": (_i, [_vp, _i, _i, _f, _f, _f, _vp]),
     "rsu_extract_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _l, _l, _vp]),
     "rsu_overlap_finish": (_i, [_vp, _vp, _vp, _l, _vp]),

@@ -40,6 +40,28 @@ hipError_t ew_pack(const float* src, void* dst, const PackParams& pp, hipStream_
 struct PackJob { PackParams pp; const float* src; bf16_t* dst; int block_start; int pad_; };
 hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hipStream_t st);
 int ew_pack_blocks(const PackParams& pp);
+// Momentum + re-pack in one pass (k_update_pack_many): one destination of a tensor's packed copies
+struct UpDest {
+    bf16_t* base[3];        // orientation B with tapmode 0/1: one buffer per segment of R1 (concat source); else base[0]
+    long tap_buf_stride;    // tapmode 2 (one single-tap matrix per source tap): elements between the matrices
+    int orient;             // 0: rows from R2, k from R1 (segmented, 32-padded); 1: rows from R1 (of one segment), k from R2
+    int ntap, tapmode;      // taps of the packed layout; 0 same tap, 1 flipped, 2 tap 0 of the tap's own matrix
+    int ntiles[3];          // 16-row tiles per (chunk, tap) of the packed layout (orientation 1: of each segment's buffer)
+    int chunk0[3];          // orientation 0: first 32-k chunk of each R1 segment
+};
+struct UpJob {
+    float* w; float* acc; const float* g;
+    long n;                 // kind 0: floats of the range
+    int kind;               // 0 plain Momentum range, 1 packed tensor
+    int ntap, R1, R2;       // source [ntap][R1][R2], R2 contiguous
+    int nseg, seg_c[3], seg_r0[3], seg_blk0[3];   // R1 segments: real rows, first row, first 32-row block
+    int nrb, ncb;           // 32-blocks along R1 (all segments) and along R2
+    int ndest;
+    UpDest d[2];
+    int block_start, pad_;
+};
+int ew_update_job_blocks(const UpJob& j);
+hipError_t ew_update_pack_many(const UpJob* jobs_dev, int njobs, int total_blocks, float lr, float mu, float gscale, hipStream_t st);
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st);

@@ -842,6 +842,118 @@ hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hi
     hipLaunchKernelGGL(k_pack_many, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs);
     return hipGetLastError();
 }
+// ---------------------------------------------------------------------------------------------
+// Momentum step + re-pack in ONE pass over the parameters (k_update_pack_many). k_momentum moves 20 B per parameter and k_pack_many
+// reads every conv kernel twice more (once per packed layout, 12 B per weight, at half the copy rate: its gathers use a quarter of
+// a sector for one of the two layouts). Here a workgroup owns 32 x 128 source elements of one tap of one tensor -- four 32 x 32
+// blocks: it reads w, acc, g once (full 128-byte rows), updates them, keeps the new weights in LDS and writes BOTH packed layouts
+// from there, each block as one contiguous 2-KiB run of 16-byte pieces: 24 B per weight, every access a full sector. Small
+// variables that no MFMA kernel reads (biases, colour adjust, the 1x1 head) are plain ranges of the same launch.
+// Source tensor = [ntap][R1][R2] float32, R2 contiguous (conv kernels HWIO: R1 = ci, R2 = co; transposed-conv kernels
+// [a][b][co][ci]: R1 = co, R2 = ci). A packed layout is [chunk of 32 k][tap][16-row tile][lane][8] (pack_range above); a
+// destination takes its ROWS from R2 and k from R1 ("orientation A": conv forward, transposed-conv backward) or rows from R1 and k
+// from R2 ("B": conv backward-data, one buffer per concat source; transposed-conv forward, one buffer per tap).
+// ---------------------------------------------------------------------------------------------
+#define UP_EPB 4096   // floats per workgroup of a plain range
+__global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restrict__ jobs, int njobs, float lr, float mu, float gscale) {
+    __shared__ int sj;
+    __shared__ float tile[4][32][33];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {  // last job whose block_start <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        sj = lo;
+    }
+    __syncthreads();
+    const UpJob& J = jobs[sj];
+    const int b = blockIdx.x - J.block_start;
+    if (J.kind == 0) {   // plain Momentum over a contiguous range (k_momentum's arithmetic)
+        const long n = J.n, n4 = n >> 2;
+        const long i0 = (long)b * (UP_EPB / 4);
+        for (int q = 0; q < UP_EPB / 4 / 256; ++q) {
+            const long i = i0 + q * 256 + threadIdx.x;
+            if (i < n4) {
+                f32x4 a = ((f32x4*)J.acc)[i], gv = ((const f32x4*)J.g)[i], wv = ((f32x4*)J.w)[i];
+                a = mu * a + gscale * gv;
+                wv -= lr * a;
+                ((f32x4*)J.acc)[i] = a;
+                ((f32x4*)J.w)[i] = wv;
+            }
+        }
+        if (b == 0 && threadIdx.x < (n & 3)) {
+            const long i = (n4 << 2) + threadIdx.x;
+            const float a = mu * J.acc[i] + gscale * J.g[i];
+            J.acc[i] = a;
+            J.w[i] -= lr * a;
+        }
+        return;
+    }
+    // ---- a packed tensor: workgroup b = (tap, row block rb, group of four column blocks cg)
+    const int ncg = (J.ncb + 3) >> 2;
+    const int cg = b % ncg, rb = (b / ncg) % J.nrb, tap = b / (ncg * J.nrb);
+    int seg = 0;
+    while (seg + 1 < J.nseg && rb >= J.seg_blk0[seg + 1]) ++seg;
+    const int rbs = rb - J.seg_blk0[seg];                // 32-row block inside its segment
+    const int r0 = J.seg_r0[seg] + rbs * 32;              // first source row
+    const int vr = min(32, J.seg_c[seg] - rbs * 32);      // real rows of the block
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int cb = cg * 4 + q, c0 = cb * 32;
+        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        if (cb < J.ncb && r < vr && c0 + c4 < J.R2) {   // (R2 is a multiple of 4: a float4 is inside or outside as a whole)
+            const long i = (((long)tap * J.R1 + r0 + r) * J.R2 + c0 + c4) >> 2;
+            f32x4 a = ((f32x4*)J.acc)[i];
+            const f32x4 gv = ((const f32x4*)J.g)[i];
+            wv = ((f32x4*)J.w)[i];
+            a = mu * a + gscale * gv;
+            wv -= lr * a;
+            ((f32x4*)J.acc)[i] = a;
+            ((f32x4*)J.w)[i] = wv;
+        }
+        tile[q][r][c4] = wv[0]; tile[q][r][c4 + 1] = wv[1]; tile[q][r][c4 + 2] = wv[2]; tile[q][r][c4 + 3] = wv[3];
+    }
+    __syncthreads();
+    // ---- both packed layouts from LDS: per (column block, destination) 128 pieces of 16 bytes = the 2 tiles of a 32-row pair
+    const int npiece = 4 * J.ndest * 128;
+    for (int pi = threadIdx.x; pi < npiece; pi += 256) {
+        const int p = pi & 127, d = (pi >> 7) % J.ndest, q = pi / (128 * J.ndest);
+        const int cb = cg * 4 + q;
+        if (cb >= J.ncb) continue;
+        const UpDest& D = J.d[d];
+        const int tl = p >> 6, lane = p & 63, rho = lane & 15, k0 = 8 * (lane >> 4);
+        const int rip = 8 * (rho >> 2) + 4 * tl + (rho & 3);   // row inside the pair of 16-row tiles
+        float v[8];
+        int chunk, pair;
+        if (D.orient == 0) {   // rows from R2 (columns of the block), k from R1 (its rows)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[q][k0 + j][rip];
+            chunk = D.chunk0[seg] + rbs;
+            pair = cb;
+        } else {               // rows from R1, k from R2
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[q][rip][k0 + j];
+            chunk = cb;
+            pair = rbs;
+        }
+        const int tapd = D.tapmode == 0 ? tap : (D.tapmode == 1 ? J.ntap - 1 - tap : 0);
+        bf16_t* base = D.base[D.orient == 0 ? 0 : (D.tapmode == 2 ? 0 : seg)] + (D.tapmode == 2 ? (long)tap * D.tap_buf_stride : 0);
+        const int ntl = D.ntiles[D.orient == 0 || D.tapmode == 2 ? 0 : seg];
+        const long e = ((((long)chunk * D.ntap + tapd) * ntl + 2 * pair + tl) << 9) + lane * 8;
+        u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        *(u32x4*)(base + e) = o;
+    }
+}
+int ew_update_job_blocks(const UpJob& j) {
+    if (j.kind == 0) return (int)((j.n + UP_EPB - 1) / UP_EPB);
+    return j.ntap * j.nrb * ((j.ncb + 3) >> 2);
+}
+hipError_t ew_update_pack_many(const UpJob* jobs_dev, int njobs, int total_blocks, float lr, float mu, float gscale, hipStream_t st) {
+    hipLaunchKernelGGL(k_update_pack_many, dim3(total_blocks), dim3(256), 0, st, jobs_dev, njobs, lr, mu, gscale);
+    return hipGetLastError();
+}
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st) {
     hipLaunchKernelGGL(k_extract_tiles, dim3(grid_for(ntiles * S * S, 256)), dim3(256), 0, st, imgs, tiles, H, S, P, stride, pps, t0, ntiles);
     return hipGetLastError();

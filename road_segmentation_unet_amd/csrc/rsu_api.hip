@@ -297,6 +297,106 @@ extern "C" int rsu_pack_table_run(const void* dev_table, int nentries, int total
     return RSU_OK;
 }
 
+// ---- Momentum + re-pack in one pass (k_update_pack_many): the table of a network's variables
+extern "C" size_t rsu_update_table_entry_bytes(void) { return sizeof(UpJob); }
+extern "C" int rsu_update_table_add_plain(void* host_table, int index, float* w, float* acc, const float* g, long n) {
+    if (!host_table || index < 0 || !w || !acc || !g || n < 1) return RSU_EINVAL;
+    if (((uintptr_t)w | (uintptr_t)acc | (uintptr_t)g) & 15) return RSU_EINVAL;
+    UpJob* t = (UpJob*)host_table + index;
+    memset(t, 0, sizeof(UpJob));
+    t->w = w; t->acc = acc; t->g = g; t->n = n; t->kind = 0;
+    return 1;
+}
+extern "C" int rsu_update_table_add(void* host_table, int index, int kind, float* w, float* acc, const float* g, void* packed_fwd,
+                                    void* const* packed_bwd, int Cin_total, int Cout, const int* seg_c, int nseg) {
+    if (!host_table || index < 0 || !w || !acc || !g || !packed_fwd || Cout % 8 || Cout < 8) return RSU_EINVAL;
+    if (((uintptr_t)w | (uintptr_t)acc | (uintptr_t)g) & 15) return RSU_EINVAL;
+    UpJob* t = (UpJob*)host_table + index;
+    memset(t, 0, sizeof(UpJob));
+    t->w = w; t->acc = acc; t->g = g; t->kind = 1;
+    int one[1] = {Cin_total};
+    if (!seg_c) { seg_c = one; nseg = 1; }
+    if (nseg < 1 || nseg > 3) return RSU_EINVAL;
+    auto set_segs = [&](const int* sc, int ns) {   // segments of R1
+        t->nseg = ns;
+        int r0 = 0, b0 = 0;
+        for (int i = 0; i < ns; ++i) {
+            t->seg_c[i] = sc[i]; t->seg_r0[i] = r0; t->seg_blk0[i] = b0;
+            r0 += sc[i];
+            b0 += cdiv(sc[i], 32);
+        }
+        t->nrb = b0;
+        return r0;
+    };
+    switch (kind) {
+        case RSU_PACK_CONV_FWD: {   // HWIO [9][Cin][Cout]: forward pack (rows co, k ci over the 32-padded sources) + one backward-data pack per source
+            if (set_segs(seg_c, nseg) != Cin_total) return RSU_EINVAL;
+            t->ntap = 9; t->R1 = Cin_total; t->R2 = Cout; t->ncb = cdiv(Cout, 32);
+            UpDest& f = t->d[0];
+            f.base[0] = (bf16_t*)packed_fwd; f.orient = 0; f.ntap = 9; f.tapmode = 0; f.ntiles[0] = rup(Cout, 128) / 16;
+            int c0 = 0;
+            for (int i = 0; i < nseg; ++i) { f.chunk0[i] = c0; c0 += cdiv(seg_c[i], 32); }
+            t->ndest = 1;
+            if (packed_bwd) {
+                UpDest& b = t->d[1];
+                b.orient = 1; b.ntap = 9; b.tapmode = 1;
+                for (int i = 0; i < nseg; ++i) {
+                    if (!packed_bwd[i]) return RSU_EINVAL;
+                    b.base[i] = (bf16_t*)packed_bwd[i];
+                    b.ntiles[i] = rup(seg_c[i], 128) / 16;
+                }
+                t->ndest = 2;
+            }
+            break;
+        }
+        case RSU_PACK_CONVT_FWD: {   // K [2][2][Cout][Cin]: four forward matrices (rows co, k ci) + the backward-data pack (rows ci, k co, 4 taps)
+            if (Cin_total % 8) return RSU_EINVAL;
+            int sc[1] = {Cout};
+            set_segs(sc, 1);
+            t->ntap = 4; t->R1 = Cout; t->R2 = Cin_total; t->ncb = cdiv(Cin_total, 32);
+            UpDest& f = t->d[0];
+            int sk[1] = {Cin_total};
+            f.base[0] = (bf16_t*)packed_fwd; f.orient = 1; f.ntap = 1; f.tapmode = 2; f.ntiles[0] = rup(Cout, 128) / 16;
+            f.tap_buf_stride = (long)(rsu_packed_bytes(1, Cout, sk, 1) / 2);
+            t->ndest = 1;
+            if (packed_bwd) {
+                if (!packed_bwd[0]) return RSU_EINVAL;
+                UpDest& b = t->d[1];
+                b.base[0] = (bf16_t*)packed_bwd[0]; b.orient = 0; b.ntap = 4; b.tapmode = 0; b.ntiles[0] = rup(Cin_total, 128) / 16; b.chunk0[0] = 0;
+                t->ndest = 2;
+            }
+            break;
+        }
+        case RSU_PACK_CONV_FIRST: {   // HWIO [9][3][Cout] over the 16-channel input tensor: forward pack only
+            int sc[1] = {3};
+            set_segs(sc, 1);
+            t->ntap = 9; t->R1 = 3; t->R2 = Cout; t->ncb = cdiv(Cout, 32);
+            UpDest& f = t->d[0];
+            f.base[0] = (bf16_t*)packed_fwd; f.orient = 0; f.ntap = 9; f.tapmode = 0; f.ntiles[0] = rup(Cout, 128) / 16; f.chunk0[0] = 0;
+            t->ndest = 1;
+            break;
+        }
+        default: return RSU_EINVAL;
+    }
+    return 1;
+}
+extern "C" int rsu_update_table_finish(void* host_table, int nentries, int* total_blocks) {
+    if (!host_table || nentries < 1 || !total_blocks) return RSU_EINVAL;
+    UpJob* t = (UpJob*)host_table;
+    int b = 0;
+    for (int i = 0; i < nentries; ++i) {
+        t[i].block_start = b;
+        b += ew_update_job_blocks(t[i]);
+    }
+    *total_blocks = b;
+    return RSU_OK;
+}
+extern "C" int rsu_update_table_run(const void* dev_table, int nentries, int total_blocks, float lr, float mu, float gscale, rsu_stream_t stream) {
+    if (!dev_table || nentries < 1 || total_blocks < 1) return RSU_EINVAL;
+    HIP_CHECK_RET(ew_update_pack_many((const UpJob*)dev_table, nentries, total_blocks, lr, mu, gscale, (hipStream_t)stream));
+    return RSU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // VALU head / tail
 // ---------------------------------------------------------------------------------------------

@@ -739,12 +739,68 @@ class UNet:
         """tf.train.exponential_decay(lr, global_step, 1000, 0.95, staircase=True) (tf_aerial_images.py:116-117), float32"""
         return float(np.float32(lr0) * np.float32(0.95) ** np.float32(self.global_step // 1000))
 
+    def _build_update_table(self):
+        """the job table of rsu_update_table_run: one entry per conv / transposed-conv kernel (with its packed copies), the variables
+        between them (biases, colour adjust, the 1x1 head) as plain Momentum ranges; covers [0, n_live) of the flat buffers once"""
+        lib = _lib.lib()
+        if not hasattr(self, "pk"):
+            self.repack()
+        entries, plain_lo, pos = [], None, 0   # ("plain", lo, hi) / ("tensor", name, kind)
+        live = sorted(((o, c, n, sh) for n, (o, c, sh) in self._slices.items() if o < self.n_live), key=lambda t: t[0])
+        for o, c, n, sh in live:
+            packed = n.endswith("kernel") and (n.startswith("up_conv") or (len(sh) == 4 and sh[0] == 3))
+            if not packed:
+                plain_lo = o if plain_lo is None else plain_lo
+                continue
+            if plain_lo is not None:
+                entries.append(("plain", plain_lo, o))
+                plain_lo = None
+            entries.append(("tensor", n, sh))
+            pos = o + c
+        if plain_lo is not None:
+            entries.append(("plain", plain_lo, self.n_live))
+        esz = lib.rsu_update_table_entry_bytes()
+        host = ctypes.create_string_buffer(esz * len(entries))
+        keep = []
+        for idx, e in enumerate(entries):
+            if e[0] == "plain":
+                lo, hi = e[1], e[2]
+                rc = lib.rsu_update_table_add_plain(host, idx, _ptr(self.flat_w[lo:hi]), _ptr(self.flat_acc[lo:hi]), _ptr(self.flat_g[lo:hi]), hi - lo)
+            else:
+                n, sh = e[1], e[2]
+                w, a, g = _ptr(self.w[n]), _ptr(self.acc[n]), _ptr(self.g[n])
+                bw = None
+                if n.startswith("up_conv"):
+                    cout, cin = sh[2], sh[3]
+                    bw = (ctypes.c_void_p * 1)(self.pk[n, "bwd"].data_ptr()) if self.training else None
+                    rc = lib.rsu_update_table_add(host, idx, 2, w, a, g, _ptr(self.pk[n, "fwd"]), bw, cin, cout, None, 0)
+                elif sh[2] == NUM_CHANNELS:
+                    rc = lib.rsu_update_table_add(host, idx, 4, w, a, g, _ptr(self.pk[n, "fwd"]), None, 3, sh[3], None, 0)
+                else:
+                    segs = self._conv_sources_c(n, sh)
+                    bw = (ctypes.c_void_p * len(segs))(*[self.pk[n, "bwd", si].data_ptr() for si in range(len(segs))]) if self.training else None
+                    rc = lib.rsu_update_table_add(host, idx, 0, w, a, g, _ptr(self.pk[n, "fwd"]), bw, sh[2], sh[3], (ctypes.c_int * len(segs))(*segs), len(segs))
+                keep.append(bw)
+            if rc != 1:
+                raise _lib.RsuError("rsu_update_table_add(%s) failed: %d" % (e[1], rc))
+        nb = ctypes.c_int(0)
+        _lib.check(lib.rsu_update_table_finish(host, len(entries), ctypes.byref(nb)), "rsu_update_table_finish")
+        self._update_table = (torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device), len(entries), nb.value)
+
     def apply_momentum(self, lr0, momentum, gscale=1.0):
-        """MomentumOptimizer step on every live variable (tf_aerial_images.py:120-121), then re-pack bf16 weights."""
-        call("rsu_momentum_step", _ptr(self.flat_w), _ptr(self.flat_acc), _ptr(self.flat_g), self.learning_rate(lr0), momentum, gscale,
-             self.n_live, self._stream())
+        """MomentumOptimizer step on every live variable (tf_aerial_images.py:120-121) and the re-pack of the bf16 MFMA copies, in one
+        pass over the parameters (rsu_update_table_run; RSU_FUSED_UPDATE=0: rsu_momentum_step, then the batched re-pack -- same bits)."""
+        if os.environ.get("RSU_FUSED_UPDATE", "1") == "0":
+            call("rsu_momentum_step", _ptr(self.flat_w), _ptr(self.flat_acc), _ptr(self.flat_g), self.learning_rate(lr0), momentum, gscale,
+                 self.n_live, self._stream())
+            self.global_step += 1
+            self.repack()
+            return
+        if getattr(self, "_update_table", None) is None:
+            self._build_update_table()
+        tab = self._update_table
+        call("rsu_update_table_run", _ptr(tab[0]), tab[1], tab[2], self.learning_rate(lr0), momentum, gscale, self._stream())
         self.global_step += 1
-        self.repack()
 
 
 _DEFAULT_MODELS = {}

@@ -115,3 +115,29 @@ def test_measured_tile_shapes_do_not_change_the_numbers():
     finally:
         call("rsu_set_autotune", 1)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("L,root,dilated,P", [(4, 32, False, 204), (3, 16, True, 60), (3, 64, True, 28), (2, 16, False, 20)])
+def test_fused_update_equals_momentum_then_repack(L, root, dilated, P, monkeypatch):
+    """rsu_update_table_run (Momentum + both packed layouts from ONE read of the weights) against rsu_momentum_step followed by the
+    batched re-pack: weights, Momentum slots and every packed buffer bit for bit, over several steps, for nets with 16-channel concat
+    segments (padded K chunks), dilated twins, transposed convs and the 3-channel first conv"""
+    from road_segmentation_unet_amd.unet import UNet
+
+    def run(fused):
+        monkeypatch.setenv("RSU_FUSED_UPDATE", "1" if fused else "0")
+        m = UNet(L, root, dilated, 2, P, seed=17, training=True)
+        g = torch.Generator(device="cpu").manual_seed(6)
+        for _ in range(3):
+            m.x.copy_(torch.rand((2, m.S, m.S, 3), generator=g))
+            m.labels.copy_((torch.rand((2, P, P), generator=g) < 0.2).to(torch.int64))
+            m.forward_device()
+            m.backward_device(1.0 / (2 * P * P))
+            m.apply_momentum(0.05, 0.9)
+        torch.cuda.synchronize()
+        return m.flat_w.clone(), m.flat_acc.clone(), {k: v.clone() for k, v in m.pk.items()}
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k].view(torch.int16), b[2][k].view(torch.int16)), k
