@@ -170,6 +170,13 @@ int rsu_head_fwd_bwd(const void* act, const float* w, const float* b, const int6
  * All sources share the window size (Hin, Win); y is bf16 [N][Hin-2d][Win-2d][Cout]. */
 int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
                    int Hin, int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream);
+/* unet.py:44-52 in one launch: y = relu(conv3x3_valid(concat(srcs), W) + b) (dilation 1), pooled = max_pooling2d(y, 2, 2) followed by
+ * the next level's dropout (keep, key as rsu_maxpool2x2_fwd), and -- code != NULL -- the code bytes of rsu_maxpool2x2_fwd_code.
+ * The conv's output size must be even. Where a tile shape with whole 2x2 windows per wavefront fits the layer and keep == 1 the
+ * pool is part of the conv kernel's epilogue (lane shuffles on the packed results; the activation is not read back from HBM);
+ * otherwise the call issues the two launches itself. Same bits either way. */
+int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
+                        int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, rsu_stream_t stream);
 /* Conv2DBackpropInput for input channels [ci_off, ci_off+ci_cnt) of a conv with Cin_total inputs:
  * dx bf16 [N][H][W][ci_cnt] (H, W = conv input size), dz bf16 [N][H-2d][W-2d][Cout].
  * relu_src (optional, same shape as dx): dx *= (relu_src > 0)  -- ReluGrad of the producing layer.

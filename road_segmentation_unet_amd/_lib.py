@@ -71,6 +71,7 @@ SIGNATURES = {
     "rsu_head_ws_floats": (_sz, [_l, _i]),
     "rsu_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_fwd_pool": (_i, [_PS, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u, _i, _vp]),
     "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -26,6 +26,8 @@ struct IgFwdParams {
     const float* bias;    // [Cout] or null
     bf16_t* out;          // [N][oH][oW][outC]
     const bf16_t* mask_src;  // same geometry as out, or null
+    bf16_t* pool_out;        // forward conv2 of an encoder level: the 2x2 max-pool of out, [N][oH/2][oW/2][outC] (igemm_pp, strip width 16 / 32), or null
+    unsigned char* pool_code;  // ... and its code bytes [N][oH/2][oW/2][outC] (k_maxpool_fwd's), or null
     const void* zero_page;   // >= 64 zero bytes
     int N, Hin, Win;      // logical input window
     int Ho, Wo;           // output pixel grid of the GEMM (before output scatter)
@@ -53,6 +55,7 @@ hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
 bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
+int igemm_pp_pool_lsw_mask(int cfg);  // strip widths (bit lsw) at which the shape can fold the 2x2 max-pool into its epilogue (0: none)
 
 // ---------------------------------------------------------------------------------------------
 // igemm_ct (igemm_ct.hip): the 2x2 stride-2 transposed convolution as a ping-pong GEMM over the low-resolution pixels m = (n, y, x)

@@ -68,7 +68,7 @@ constexpr int pp_na_idx(int NAW, int g, int j) {  // index of the slot's first p
     return n;
 }
 }  // namespace
-template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG>
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG, bool POOLK = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 igemm_pp_kernel(const IgFwdParams p) {
     constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
@@ -347,6 +347,83 @@ igemm_pp_kernel(const IgFwdParams p) {
         ovoff[pt] = (unsigned)(((ty * p.oW + tx) * p.outC + 8 * g4) * 2);
     }
     const bool co_inside = cob * TN + TN <= p.Cout;
+    // ---- 2x2 max-pool folded into the epilogue (unet.py:44-52: conv2 + ReLU, then max_pooling2d). A wave's PT fragments are PT * 16
+    // consecutive pixels of the tile = whole rows of the strip when the strip is 16 or 32 wide: the two rows of a 2x2 window are two
+    // fragments of the SAME wave (PT = 4: fragments (0,2),(1,3) at width 32, (0,1),(2,3) at width 16; PT = 2, width 16: (0,1)), its two
+    // columns neighbouring lanes. On the packed, post-ReLU bf16 words (non-negative: integer order = float order) the vertical max is
+    // one v_pk_max_i16 per dword, the horizontal one a DPP lane swap + max; the even lanes store the pooled pixel (16 bytes) and its
+    // code bytes (k_maxpool_fwd's: bits 0-3 window element > 0, bits 4-5 first maximum in row-major order).
+    // (POOLK: the pooling epilogue lives in instantiations of its own -- inside the others it cost the main loop 5-6 spilled registers)
+    constexpr bool POOL_OK = POOLK && ((PT == 4 && (LSW == 4 || LSW == 5)) || (PT == 2 && LSW == 4));
+    auto pool_body = [&](const Tile& T, f32x4(&acc)[CT][PT], const unsigned (&voffs)[NST], const __amdgpu_buffer_rsrc_t orsrc, const unsigned sbase)
+                         __attribute__((always_inline)) {
+        typedef __attribute__((ext_vector_type(2))) short s2;
+        typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+        constexpr int NPAIR = PT / 2, PSTEP = (LSW == 5) ? 2 : 1;   // fragment pa's row partner is fragment pa + PSTEP
+        const int pH = p.oH >> 1, pW = p.oW >> 1;
+        const __amdgpu_buffer_rsrc_t prsrc = mk(p.pool_out);
+        const __amdgpu_buffer_rsrc_t crsrc = mk(p.pool_code ? (const void*)p.pool_code : (const void*)p.pool_out);
+        const unsigned psbase = (unsigned)((((long)(T.n * pH + (T.y0 >> 1)) * pW + (T.x0 >> 1)) * p.outC + cob * TN + wco * (CT / 2) * 32) * 2);
+        const short fl = p.relu ? (short)0 : (short)-32768;
+        const s2 floor2 = {fl, fl};
+        auto pk = [&](int ct2, int pt) {
+            u32x4 r;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned lo = pack_bf2(acc[ct2][pt][2 * i], acc[ct2][pt][2 * i + 1]);
+                const unsigned hi = pack_bf2(acc[ct2 + 1][pt][2 * i], acc[ct2 + 1][pt][2 * i + 1]);
+                r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+            }
+            return r;
+        };
+        auto swap1 = [](unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };   // quad_perm [1,0,3,2]: lane ^ 1
+        auto umin1 = [](unsigned v) {   // per 16-bit half: 1 where the half is non-zero
+            const us2 one = {1, 1};
+            return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, v), one));
+        };
+        auto sub16 = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); };
+        auto mul16 = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, b))); };
+        auto add16 = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b))); };
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int pa = (LSW == 5) ? q : 2 * q, pb = pa + PSTEP;
+            // pooled pixel of this lane's window (even lanes): row ty / 2, column tx / 2 of the tile's pooled block
+            const int ml = (wpx * PT + pa) * 16 + l15;
+            const int ty = ml >> lsw, tx = ml & (SW - 1);
+            const bool pok = ((l15 & 1) == 0) && (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
+            const unsigned pvoff = (unsigned)((((ty >> 1) * pW + (tx >> 1)) * p.outC + 8 * g4) * 2);
+#pragma unroll
+            for (int pp = 0; pp < CT / 2; ++pp) {
+                const u32x4 ra = pk(2 * pp, pa), rb = pk(2 * pp, pb);
+                PP_STORE(ra, voffs[pa * (CT / 2) + pp]);
+                PP_STORE(rb, voffs[pb * (CT / 2) + pp]);
+                u32x4 pooled;
+                unsigned cw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned v00 = ra[i], v10 = rb[i], v01 = swap1(ra[i]), v11 = swap1(rb[i]);
+                    const unsigned mv = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, v00), __builtin_bit_cast(s2, v10)));
+                    const unsigned mh = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, v01), __builtin_bit_cast(s2, v11)));
+                    const unsigned mx = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, mv), __builtin_bit_cast(s2, mh)));
+                    pooled[i] = mx;
+                    // code: (element > 0) bits, then the first element that equals the maximum: ne_k = (mx - v_k != 0)
+                    const unsigned g = umin1(v00) | (umin1(v01) << 1) | (umin1(v10) << 2) | (umin1(v11) << 3);
+                    const unsigned ne0 = umin1(sub16(mx, v00)), ne1 = umin1(sub16(mx, v01)), ne2 = umin1(sub16(mx, v10));
+                    const unsigned idx = mul16(ne0, add16(0x00010001u, mul16(ne1, add16(0x00010001u, ne2))));
+                    cw[i] = g | (idx << 4);
+                }
+                const bool cok = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4 < p.Cout;
+                const unsigned pv = (pok && cok) ? pvoff + pp * 64 : RSU_SENT;
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(pooled), "v"(pv), "s"(prsrc), "s"(psbase) : "memory");
+                if (p.pool_code) {
+                    u32x2 cd = {__builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u), __builtin_amdgcn_perm(cw[3], cw[2], 0x06040200u)};
+                    const unsigned cv = (pok && cok) ? (pvoff + pp * 64) >> 1 : RSU_SENT;
+                    asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(cd), "v"(cv), "s"(crsrc), "s"(psbase >> 1) : "memory");
+                }
+            }
+        }
+    };
     auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
@@ -409,6 +486,12 @@ igemm_pp_kernel(const IgFwdParams p) {
                     }
                 }
             };
+            if constexpr (POOL_OK) {
+                if (p.pool_out) {   // (wave-uniform) forward conv2 of an encoder level: y, the 2x2 max-pool of y and its code bytes
+                    pool_body(T, acc, voffs, orsrc, sbase);
+                    return;
+                }
+            }
             if (p.mask_src) body(true); else body(false);
             return;
         }
@@ -657,9 +740,9 @@ template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX =
 template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NAS = PP_NAS(0, 3, 3, 2, 2), WP0 = 0; };
 // (128x320 / 64x640, five pixel fragments per wave: measured 20-40 % slower than igemm_fwd2's -- three taps of fragments beside 80
 // accumulators leave no registers for the tile bookkeeping; not instantiated)
-template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG>
-static hipError_t pp_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
-    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG>;
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG, bool POOLK = false>
+static hipError_t pp_launch_kernel3(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG, POOLK>;
     const size_t lds = igemm_fwd2_lds_bytes(cfg, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -669,6 +752,14 @@ static hipError_t pp_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipSt
     }
     hipLaunchKernelGGL(kern, dim3(gx, 1), dim3(512), lds, st, p);
     return hipGetLastError();
+}
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG>
+static hipError_t pp_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
+    if constexpr (!STAMP && !DBG && ((PT == 4 && (LSW == 4 || LSW == 5)) || (PT == 2 && LSW == 4))) {
+        if (p.pool_out) return pp_launch_kernel3<WCO, WPX, CT, PT, LSW, NAS, WP0, false, false, true>(cfg, p, gx, st);
+    }
+    if (p.pool_out) return hipErrorInvalidValue;   // (the planner only asks for the pool where igemm_pp_pool_lsw_mask allows it)
+    return pp_launch_kernel3<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG, false>(cfg, p, gx, st);
 }
 // strip widths an instantiation exists for: the halo tile must fit the DMA pieces of a chunk and the 16-bit offsets of the LDS reads
 constexpr bool pp_geo_ok(int TM, int LSW, int NAS) {
@@ -718,6 +809,14 @@ bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
 #undef PP_CASE
     }
     return pp_geo_ok(TM, p.lsw, nas);
+}
+// (PT = 4: whole rows per wave at widths 16 and 32; PT = 2: at width 16 -- igemm_pp_kernel POOL_OK)
+int igemm_pp_pool_lsw_mask(int cfg) {
+    switch (cfg) {
+        case IGF2_CFG_128x256: case IGF2_CFG_64x512: return (1 << 4) | (1 << 5);
+        case IGF2_CFG_128x128: case IGF2_CFG_64x256: return 1 << 4;
+    }
+    return 0;
 }
 // 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {

@@ -130,13 +130,15 @@ extern "C" int rsu_input_size_needed(int output_size, int num_layers, int* input
 // ---------------------------------------------------------------------------------------------
 // Strip width for a Ho x Wo pixel grid cut into aligned TM-pixel tiles: SW is a power of two dividing TM; a tile is TM/SW full rows
 // of a strip; npix_cap = LDS pixels available for the halo tile.
-static bool plan_geo_aligned(TileGeo& best, int& lsw_out, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap) {
+static bool plan_geo_aligned(TileGeo& best, int& lsw_out, int Ho, int Wo, int TM, int kh, int kw, int dil, int stride, int npix_cap,
+                             int lsw_mask = 0) {
     if (Ho < 1 || Wo < 1) return false;
     double best_cost = 1e30;
     bool found = false;
     for (int lsw = 3; lsw <= 6; ++lsw) {
         const int SW = 1 << lsw;
         if (SW > TM) break;
+        if (lsw_mask && !(lsw_mask & (1 << lsw))) continue;   // (only these strip widths: the launch folds the max-pool into its epilogue)
         const int TR = TM / SW;
         TileGeo g;
         g.SW = SW;
@@ -416,9 +418,9 @@ extern "C" int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsig
 // igemm_fwd family
 // ---------------------------------------------------------------------------------------------
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
-struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; };
+struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; double cost; };
 static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
-                      int force_cfg, bool shared_chip = false) {
+                      int force_cfg, bool shared_chip = false, bool pool = false) {
     double best_cost = 1e300;
     bool have = false;
     // pass 0: channel-block width matched to Cout; pass 1 (only when no such shape fits its halo tile into LDS -- the 2x2 stride-2
@@ -431,6 +433,8 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
         const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
         if (pass == 0 && Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
         if (pass == 0 && Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
+        const int lsw_mask = pool ? igemm_pp_pool_lsw_mask(cfg) : 0;
+        if (pool && !lsw_mask) continue;
         const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
         const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, ntap, 1) - fixed;  // 64 bytes x halo ring slots
         int cap = (int)((160 * 1024 - fixed) / per_pix);
@@ -438,7 +442,7 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
         if (cap2 < cap) cap = cap2;
         TileGeo g;
         int lsw = 0;
-        if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap)) continue;
+        if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, kh, kw, dil, stride, cap, lsw_mask)) continue;
         const int ncob = cdiv(Cout, ci.TN);
         const long ntile_m = (long)N * g.nstrips * g.tiles_per_strip;
         long workers = ncu / (ncob * gy);  // blockIdx.y slices (transposed-conv phases) share the chip
@@ -466,6 +470,7 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
             best.ncob = ncob;
             best.grid_x = (int)(workers * ncob);
             best.lsw = lsw;
+            best.cost = cost;
             have = true;
         }
     }
@@ -482,8 +487,10 @@ static hipError_t launch_persistent(int pp, int cfg, int ntap, const IgFwdParams
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
-                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, int ncu_arg, hipStream_t st) {
+                   int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, int ncu_arg, hipStream_t st,
+                   void* pool_out = nullptr, void* pool_code = nullptr) {
     const int kh = ntap / kw;
+    const bool pool = pool_out != nullptr;
     const int ncu = launch_ncu(ncu_arg);
     if (ncu < 0) return RSU_EINVAL;
     const long out_bytes = (long)N * oH * oW * outC * 2;
@@ -505,7 +512,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     const int tune_mode = env_int("RSU_AUTOTUNE", 1) != 0 ? g_autotune.load() : RSU_TUNE_OFF;
     const bool tunable = env_cfg < 0 && !accumulate && tune_mode != RSU_TUNE_OFF;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
-                                (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0), ostride, ncu * 8 + gen};
+                                (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (pool ? 8 : 0) | (pool_code ? 16 : 0), ostride, ncu * 8 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
     bool tune_now = false;
     if (tunable) {
@@ -518,7 +525,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             tune_now = tune_mode == RSU_TUNE_MEASURE;
         }
     }
-    if (!plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip)) {
+    if (!plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip, pool)) {
         // a shape forced through RSU_FWD2_CFG, or a tuned shape (an imported table), whose halo tile does not fit this geometry: plan
         // freely instead (and forget the table entry)
         if (tuned_cfg >= 0) {
@@ -526,7 +533,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             g_tuned.erase(tkey);
             tuned_pp = -1;
         }
-        if (!((env_cfg >= 0 || tuned_cfg >= 0) && plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip)))
+        if (!((env_cfg >= 0 || tuned_cfg >= 0) && plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, -1, shared_chip, pool)))
             return RSU_EINVAL;
     }
     IgFwdParams p;
@@ -550,6 +557,8 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     p.bias = bias;
     p.out = (bf16_t*)out;
     p.mask_src = (const bf16_t*)mask_src;
+    p.pool_out = (bf16_t*)pool_out;
+    p.pool_code = (unsigned char*)pool_code;
     p.zero_page = zero_page();
     if (!p.zero_page) return RSU_EHIP;
     p.N = N; p.Hin = Hin; p.Win = Win; p.Ho = Ho; p.Wo = Wo;
@@ -560,7 +569,8 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     {
         // kernel generation: the ping-pong kernel wherever it is instantiated (measured 10-20 % faster than igemm_fwd2 at every
         // shape; launch_persistent falls back to igemm_fwd2 for the rest) unless the tuner measured otherwise for this geometry
-        const int pp = (pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0)) ? 1 : 0;
+        const int pp = (pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0 || pool)) ? 1 : 0;
+        if (pool && !pp) return RSU_EINVAL;
         p.ncob = pl2.ncob;
         p.g = pl2.g;
         p.lsw = pl2.lsw;
@@ -602,13 +612,14 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             for (int cfg = 0; cfg < IGF2_NCFG; ++cfg) {
                 if (igemm_fwd2_cfg_info(cfg).TN != tn_model) continue;
                 Fwd2Plan pc;
-                if (!plan_fwd2(pc, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip)) continue;
+                if (!plan_fwd2(pc, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip, pool)) continue;
                 IgFwdParams pt = p;
                 pt.ncob = pc.ncob;
                 pt.g = pc.g;
                 pt.lsw = pc.lsw;
                 for (int vpp = 0; vpp < 2; ++vpp) {  // the kernel generations of the shape
                     if (vpp == 1 && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
+                    if (vpp == 0 && pool) continue;   // (only the ping-pong kernel folds the pool)
                     if (!vpp && gen >= 4 && pp_ok && igemm_pp_supports(cfg, pt)) continue;
                     float ms_min = 1e30f;
                     for (int rep = 0; rep < 6; ++rep) {
@@ -649,6 +660,36 @@ extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packe
     if (Ho < 1 || Wo < 2) return RSU_EINVAL;
     return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
                    Ho, Wo, 1, 1, relu, 0, ncu, (hipStream_t)stream);
+}
+
+extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
+                                   int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, rsu_stream_t stream) {
+    if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !pooled || Cout % 8 || !keep_ok(keep)) return RSU_EINVAL;
+    const int Ho = Hin - 2, Wo = Win - 2;
+    if (Ho < 2 || Wo < 2 || ((Ho | Wo) & 1)) return RSU_EINVAL;
+    // the pool folds into the conv's epilogue where a ping-pong tile shape with whole window rows per wave fits the layer and no dropout
+    // follows (its mask is a function of the pooled element index: the separate kernel applies it); otherwise: the two launches
+    // ... and where the shapes that can fold it (strip width 16 / 32) cost the conv no extra round of tiles: the pool kernel it saves
+    // is short (measured: profiles/r03/pool_fusion.txt; RSU_POOL_FUSED=2 folds wherever a shape exists, 0 never)
+    const int fuse = env_int("RSU_POOL_FUSED", 1);
+    bool worth = fuse >= 2;
+    if (fuse == 1) {
+        Fwd2Plan a, b;
+        const int n = launch_ncu(ncu), kt = 0;
+        int ktot = 0;
+        for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * 9;
+        (void)kt;
+        worth = n > 0 && plan_fwd2(a, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, false) &&
+                plan_fwd2(b, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, true) && b.cost <= 1.02 * a.cost;
+    }
+    if (keep == 1.f && worth && env_int("RSU_FWD_GEN", 3) >= 3 && env_int("RSU_FWD2_CFG", -1) < 0) {
+        const int rc = run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, 1, 1, 0, Ho, Wo,
+                               1, 1, 1, 0, ncu, (hipStream_t)stream, pooled, code);
+        if (rc != RSU_EINVAL) return rc;
+    }
+    const int rc = rsu_conv2d_fwd(srcs, nsrc, packed_fwd, bias, y, N, Hin, Win, Cout, 1, 1, ncu, stream);
+    if (rc != RSU_OK) return rc;
+    return rsu_maxpool2x2_fwd_code(y, pooled, code, N, Ho, Wo, Cout, keep, key, stream);
 }
 
 extern "C" size_t rsu_packed_first_bytes(int Cout) {

@@ -474,11 +474,17 @@ class UNet:
                 self._conv_first("conv_0/conv1", a["c1_0"], h, 1, st)
             else:
                 self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i])
-            self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
-            if not last:
-                c2 = a["c2_%d" % i]
-                call("rsu_maxpool2x2_fwd_code", _ptr(c2), _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 4, h - 4, c2.shape[3], keep,
-                     self.dropout_key(i + 1), st)
+            if last:
+                self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
+            else:
+                # conv2 + ReLU + the level's 2x2 max-pool (+ the next level's dropout, + the code bytes of the gradient junction): one
+                # call, one launch where the pool folds into the conv's epilogue (rsu.h rsu_conv2d_fwd_pool)
+                c1, c2 = a["c1_%d" % i], a["c2_%d" % i]
+                nf_ = c2.shape[3]
+                src = (RsuSrc * 1)(_src(c1, h - 2, h - 2))
+                self._timed("conv3x3_fwd", 2.0 * B * (h - 4) * (h - 4) * nf_ * c1.shape[3] * 9, "rsu_conv2d_fwd_pool", src, 1,
+                            _ptr(self.pk["conv_%d/conv2/kernel" % i, "fwd"]), _ptr(self.w["conv_%d/conv2/bias" % i]), _ptr(c2),
+                            _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 2, h - 2, nf_, keep, self.dropout_key(i + 1), self._ncu, st)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
         if self.dilated:

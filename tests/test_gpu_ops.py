@@ -288,6 +288,47 @@ def test_wgrad_group_equals_single_launches(ncu):
             hu.assert_f32_close(gdb, rdb, "group convT bias grad")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 70, 70, 64, 64), (1, 138, 138, 64, 128), (2, 34, 50, 128, 256), (1, 66, 66, 32, 64),
+                                            (1, 282, 150, 64, 64), (3, 22, 22, 64, 192)])
+def test_conv2d_fwd_pool_equals_conv_then_pool(N, H, W, Cin, Cout, monkeypatch):
+    """rsu_conv2d_fwd_pool (the 2x2 max-pool and its code bytes folded into the conv epilogue: lane swaps on the packed results) against
+    rsu_conv2d_fwd followed by rsu_maxpool2x2_fwd_code: activation, pooled tensor and code bytes bit for bit, partial tiles at the image
+    edges included; with dropout (keep < 1) and with RSU_POOL_FUSED=0 the call issues the two launches itself: same bits again"""
+    rng = np.random.RandomState(N * 7 + H + Cout)
+    x = hu.q(_rand(rng, N, H, W, Cin))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    xd, wp, bd = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b)
+    Ho, Wo = H - 2, W - 2
+    s = (RsuSrc * 1)(hu.src_of(xd, H, W))
+
+    def run(fused, keep=1.0, key=0):
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        pool = torch.full((N, Ho // 2, Wo // 2, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        code = torch.full((N, Ho // 2, Wo // 2, Cout), 0xAA, dtype=torch.uint8, device=hu.DEV)
+        if fused:
+            call("rsu_conv2d_fwd_pool", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), hu.ptr(pool), hu.ptr(code), N, H, W, Cout, keep, key, 0, hu.stream())
+        else:
+            call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, 1, 1, 0, hu.stream())
+            call("rsu_maxpool2x2_fwd_code", hu.ptr(y), hu.ptr(pool), hu.ptr(code), N, Ho, Wo, Cout, keep, key, hu.stream())
+        torch.cuda.synchronize()
+        return y.view(torch.int16).cpu().numpy(), pool.view(torch.int16).cpu().numpy(), code.cpu().numpy()
+
+    ref = run(False)
+    monkeypatch.setenv("RSU_POOL_FUSED", "2")   # fold wherever a tile shape can (the default folds only where it costs the conv no extra round)
+    got = run(True)
+    for a, r, what in zip(got, ref, ("activation", "pooled", "code bytes")):
+        np.testing.assert_array_equal(a, r, err_msg=what)
+    assert float((ref[1] != 0).mean()) > 0.3
+    ref_d, got_d = run(False, 0.8, 1234), run(True, 0.8, 1234)
+    for a, r in zip(got_d, ref_d):
+        np.testing.assert_array_equal(a, r)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RSU_POOL_FUSED", mode)
+        for a, r in zip(run(True), ref):
+            np.testing.assert_array_equal(a, r)
+
+
 # ------------------------------------------------------------------------------------------- first layer
 @pytest.mark.parametrize("dil,keep", [(1, 1.0), (2, 1.0), (1, 0.8)])
 def test_color_adjust_and_first_conv(dil, keep):
