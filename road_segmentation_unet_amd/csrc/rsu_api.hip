@@ -680,7 +680,7 @@ extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* 
         for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * 9;
         (void)kt;
         worth = n > 0 && plan_fwd2(a, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, false) &&
-                plan_fwd2(b, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, true) && b.cost <= 1.02 * a.cost;
+                plan_fwd2(b, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, true) && b.cost <= 1.08 * a.cost;
     }
     if (keep == 1.f && worth && env_int("RSU_FWD_GEN", 3) >= 3 && env_int("RSU_FWD2_CFG", -1) < 0) {
         const int rc = run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, 1, 1, 0, Ho, Wo,
@@ -1036,7 +1036,7 @@ extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, floa
             const double target = W / ncu / ks[ki];
             int split[IGW_GROUP_MAX];
             std::vector<double> units;
-            double slabs = 0.0, ws_need = 0.0;
+            double ws_need = 0.0;
             for (int i = 0; i < n; ++i) {
                 double s = (double)it[i].w.ntiles * it[i].cost / (target > 0 ? target : 1.0);
                 int ns = s < 1.4 ? 1 : (int)(s + 0.5);
@@ -1046,7 +1046,6 @@ extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, floa
                 const double unit = (double)cdiv(it[i].w.ntiles, ns) * it[i].cost + (ns > 1 ? slab_cost : 0.0);
                 for (int u = 0; u < it[i].blocks * ns; ++u) units.push_back(unit);
                 if (ns > 1) {
-                    slabs += (double)it[i].blocks * ns;
                     ws_need += (double)ns * (double)(it[i].w.main_elems + it[i].w.extra);
                 }
             }

@@ -175,6 +175,69 @@ def test_config3_full_size_dilated_backward_layers_match_oracle():
     print("c3 backward, layer by layer at full size:", {k: "%.2e" % v for k, v in worst.items()})
 
 
+def test_config4_share_full_size_backward_layers_match_oracle():
+    """config 4's network (L=6, root 64, NOT dilated, 764 -> 388), two patches, BACKWARD at full size, layer by layer like the config-3
+    test above: the deepest block (1024 -> 2048 -> 2048 at 20 -> 16 px), the widest concat (conv_6/conv1: 2 x 1024 -> 1024) and the
+    full-resolution decoder stage (conv_10: 128 -> 64 -> 64 at 392 px) -- weight / bias gradients and backward-data against the oracle's
+    layer operators on the tensors of the HIP pass"""
+    L, root, P, B = 6, 64, 388, 2
+    S = U.input_size_needed(P, L)
+    rng = np.random.RandomState(71)
+    x = rng.rand(B, S, S, 3).astype(np.float32)
+    labels = (rng.rand(B, P, P) < 0.2).astype(np.int64)
+    params = U.init_params(L, root, False, seed=72, bias_scale=0.02)
+    net = UNet(L, root, False, B, P, params=params, training=True)
+    net.x.copy_(torch.from_numpy(x))
+    net.labels.copy_(torch.from_numpy(labels))
+    net.forward_device()
+    net.backward_device(1.0 / (B * P * P))
+    torch.cuda.synchronize()
+
+    def act(k):
+        return net.act[k].float().cpu().numpy()
+
+    def grd(k):
+        return net.grad[k].float().cpu().numpy()
+
+    worst = {}
+
+    def check_w(name, xin, dz):
+        rdw, rdb = U.conv2d_bwd_weight(xin, dz)
+        gw, gb = net.g[name + "/kernel"].cpu().numpy(), net.g[name + "/bias"].cpu().numpy()
+        hu.assert_f32_close(gw, rdw, name + " weight gradient", rtol=2e-4, atol_scale=2e-5)
+        hu.assert_f32_close(gb, rdb, name + " bias gradient", rtol=2e-4, atol_scale=2e-5)
+        worst[name + "/wgrad_rel"] = float(np.linalg.norm(gw - rdw) / np.linalg.norm(rdw))
+
+    def check_dx(name, dz, w, in_hw, got, mask=None, what=""):
+        ref = U.conv2d_bwd_data(dz, hu.q(w), in_hw)
+        if mask is not None:
+            ref = U.relu_bwd(mask, ref)
+        hu.assert_bf16_close(got, ref, name + " backward-data" + what)
+        worst[name + "/bwd_data_rel" + what] = float(np.linalg.norm(got - hu.q(ref)) / max(np.linalg.norm(ref), 1e-30))
+
+    # the deepest block: conv_5/conv2 (2048 -> 2048) and conv_5/conv1 (1024 -> 2048 on the pooled level-4 tensor)
+    c1, dz2 = act("c1_5"), grd("c2_5")
+    check_w("conv_5/conv2", c1, dz2)
+    check_dx("conv_5/conv2", dz2, params["conv_5/conv2/kernel"], c1.shape[1:3], grd("c1_5"), mask=c1)
+    check_w("conv_5/conv1", act("pool_4"), grd("c1_5"))
+    # conv_6/conv1: concat [skip 1024, up 1024] -> 1024
+    h = net.act["up_0"].shape[1]
+    cat = np.concatenate([U.center_crop(act("c2_4"), h, h), act("up_0")], axis=3)
+    dz1 = grd("c1_6")
+    check_w("conv_6/conv1", cat, dz1)
+    check_dx("conv_6/conv1", dz1, params["conv_6/conv1/kernel"][:, :, 1024:2048, :], (h, h), grd("up_0"), what=" (up source)")
+    check_dx("conv_6/conv1", dz1, params["conv_6/conv1/kernel"][:, :, 0:1024, :], (h, h), grd("skip_0"), what=" (skip source)")
+    # conv_10: the full-resolution decoder stage
+    c1, dz2 = act("c1_10"), grd("c2_10")
+    check_w("conv_10/conv2", c1, dz2)
+    check_dx("conv_10/conv2", dz2, params["conv_10/conv2/kernel"], c1.shape[1:3], grd("c1_10"), mask=c1)
+    h = net.act["up_4"].shape[1]
+    cat = np.concatenate([U.center_crop(act("c2_0"), h, h), act("up_4")], axis=3)
+    check_w("conv_10/conv1", cat, grd("c1_10"))
+    record("c4_backward_layers_full_size", **worst)
+    print("c4 backward, layer by layer at full size:", {k: "%.2e" % v for k, v in worst.items()})
+
+
 def test_real_388_patches_pixel_f1_within_1e3_of_the_float32_oracle():
     """The north_star's F1 claim on 388-px patches: the 16 held-out 388-patches (4 real 400-px images of the reference's training set,
     stride 12: 2.4 M pixels) through an L=5, root=16 U-Net trained on the other 96 images (tests/golden/real388_trained_params.npz,

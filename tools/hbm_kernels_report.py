@@ -16,14 +16,18 @@ for i in range(L - 1):
     pool_in.append(B * (h - 4) ** 2 * nf)
     h, nf = (h - 4) // 2, nf * 2
 n_pool_in = sum(pool_in)
+# levels whose pool still runs as a kernel of its own (round 3: levels 1 and 3 fold it into conv2's epilogue, rsu_conv2d_fwd_pool);
+# overridable: POOL_LEVELS="0,1,2,3"
+import os
+pool_levels = [int(v) for v in os.environ.get("POOL_LEVELS", "0,2").split(",")]
+n_pool_kernel = sum(pool_in[i] for i in pool_levels)
 n_param = 31031822
 npix_out, npix_in = B * P * P, B * S * S
 alg = {  # kernel-name prefix -> (what, bytes per step)
-    "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout) + code byte: 2 B read + 0.5 B + 0.25 B written per input element", 2.75 * n_pool_in),
+    "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout) + code byte, levels %s: 2 B read + 0.5 B + 0.25 B written per input element" % pool_levels, 2.75 * n_pool_kernel),
     "_Z20k_pool_skip_relu_bwd": ("pool bwd + skip-gradient add + ReLU mask from the code bytes: 0.25 B code + 0.5 B dpool + ~1 B dskip (the "
                                  "cropped window) read, 2 B dz written per input element", 3.8 * n_pool_in),
-    "_Z10k_momentum": ("Momentum step: w, a, g read, w, a written (20 B per parameter)", 20.0 * n_param),
-    "_Z11k_pack_many": ("f32 -> bf16 MFMA fragment order, forward + backward pack (4 B read once per pack + 2 B written)", 12.0 * n_param),
+    "_Z18k_update_pack_many": ("Momentum step + re-pack in one pass: w, a, g read, w, a written, both bf16 packed layouts written (24 B per weight)", 24.0 * n_param),
     "_Z6k_head": ("1x1 head + softmax + CE + gradients: 128 B read + 128 B written per output pixel", 256.0 * npix_out),
     "_Z14k_color_adjust": ("centre + colour adjust: 12 B read + 32 B written per input pixel", 44.0 * npix_in),
 }

@@ -33,7 +33,7 @@ if dbs:
     ks = [t for t in tabs if "kernel_symbol" in t][0]
     rows = cur.execute(f"select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
-    nsteps = max([c for n, c, *_ in rows if "k_momentum" in n] + [0])
+    nsteps = max([c for n, c, *_ in rows if "k_color_adjust" in n and "bwd" not in n] + [1])   # one colour adjust per forward pass
     with open("$OUT/kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])

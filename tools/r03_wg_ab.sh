@@ -1,16 +1,25 @@
 #!/bin/bash
-# usage (GPU box): tools/r03_wg_ab.sh -> gpurun_out/r03b/: the grouped weight-gradient launches (RSU_WG_GROUP) against per-layer launches
+# usage (GPU box): [SPECS="0 1 2 ..."] tools/r03_wg_ab.sh -> gpurun_out/r03b/wg_group_schedules.txt: the two-stream step under different groupings of
+# the weight gradients (RSU_WG_GROUP = blocks per group; 0 = one launch per layer) and the single-stream schedule, same box, alternating
 OUT=gpurun_out/r03b; mkdir -p $OUT
-if [ -z "$NOTESTS" ]; then
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -k "wgrad_group or bwd_weight or pingpong_wgrad" > $OUT/t_ops.log 2>&1; tail -3 $OUT/t_ops.log
-timeout 900 python -m pytest tests/test_gpu_net.py tests/test_gpu_soak.py tests/test_gpu_dp.py -x -q > $OUT/t_net.log 2>&1; tail -3 $OUT/t_net.log
-fi
-for G in ${SPECS:-0 1 5,4 4,5 3,3,3 2,3,4 all}; do
+TAB=$OUT/wg_group_schedules.txt
+echo "bench.py --no_cpu_baseline --sustain_seconds 0 under RSU_WG_GROUP (two-stream timed region; the serialised roofline pass uses the same grouping), one box:" > $TAB
+for rep in 1 2; do
+for G in ${SPECS:-0 1 2 3 3,3,3 5,4 all}; do
   RSU_WG_GROUP=$G python bench.py --no_cpu_baseline --sustain_seconds 0 > $OUT/bench_g$G.json 2> $OUT/bench_g$G.err
-  python - <<PY
+  python - >> $TAB <<PY
 import json
 d=json.load(open("$OUT/bench_g$G.json"))
-r=d["roofline"]
-print("G=$G value %.1f ms %.3f frac %.4f conv_ms %.3f" % (d["value"], d["ms_per_step"], r["frac"], r["conv_ms_per_step"]), {k:(round(v["ms_per_step"],3),v["launches"]) for k,v in r["by_kernel"].items()})
+r=d["roofline"]; w=r["by_kernel"]["conv3x3_bwd_weight"]
+print("RSU_WG_GROUP=%-6s %7.1f patches/s  %.3f ms/step | serialised pass: weight gradients %.3f ms in %2d launches, roofline.frac %.4f" % ("$G", d["value"], d["ms_per_step"], w["ms_per_step"], w["launches"], r["frac"]))
 PY
 done
+RSU_WGRAD_STREAM=0 python bench.py --no_cpu_baseline --sustain_seconds 0 > $OUT/bench_1stream.json 2> $OUT/bench_1stream.err
+python - >> $TAB <<PY
+import json
+d=json.load(open("$OUT/bench_1stream.json"))
+r=d["roofline"]; w=r["by_kernel"]["conv3x3_bwd_weight"]
+print("one stream (grouped)  %7.1f patches/s  %.3f ms/step | serialised pass: weight gradients %.3f ms in %2d launches, roofline.frac %.4f" % (d["value"], d["ms_per_step"], w["ms_per_step"], w["launches"], r["frac"]))
+PY
+done
+cat $TAB
