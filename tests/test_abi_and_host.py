@@ -44,6 +44,33 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in src.lower().replace("test oracle", ""), "product file %s mentions the oracle" % fn
 
 
+def test_host_side_abi_rules_without_a_gpu():
+    """entry points that are pure host code: the tuning-mode switch, the validation of imported tuning tables (rows naming a tile shape
+    or kernel generation this build does not have are skipped: ADVICE r2), the CU-budget range, table sizes"""
+    from road_segmentation_unet_amd import _lib
+    L = _lib.lib()
+    assert L.rsu_get_autotune() == _lib.TUNE_LOOKUP            # launches look shapes up, they never measure by default
+    assert L.rsu_set_autotune(3) == -22 and L.rsu_set_autotune(-1) == -22
+    assert L.rsu_set_autotune(_lib.TUNE_MEASURE) == 0 and L.rsu_get_autotune() == _lib.TUNE_MEASURE
+    assert L.rsu_set_autotune(_lib.TUNE_LOOKUP) == 0
+    n0 = L.rsu_autotune_entries()
+    key = list(range(100, 116))
+    rows = (ctypes.c_int * (17 * 5))(*(key + [0] + key[:-1] + [7] + [1 | (1 << 8)]          # shape 0 (igemm_fwd2); shape 1 on igemm_pp
+                                       + key[:-1] + [8] + [99]                                # no such shape
+                                       + key[:-1] + [9] + [0 | (5 << 8)]                      # no such kernel generation
+                                       + key[:-1] + [10] + [6 | (1 << 8)]))                   # igemm_pp is not built for shape 6
+    assert L.rsu_autotune_import(rows, 5) == 2
+    assert L.rsu_autotune_entries() == n0 + 2
+    assert L.rsu_set_cu_budget(16) == -22 and L.rsu_set_cu_budget(300) == -22
+    assert L.rsu_get_cu_budget() == 256
+    assert L.rsu_wgrad_group_table_bytes() > 0 and L.rsu_wgrad_group_ws_floats() > 0 and L.rsu_update_table_entry_bytes() > 0
+    host = ctypes.create_string_buffer(L.rsu_update_table_entry_bytes() * 2)
+    assert L.rsu_update_table_add_plain(host, 0, 16, 32, 48, 100) == 1          # (pointers are only recorded: 16-byte aligned dummies)
+    assert L.rsu_update_table_add_plain(host, 1, 17, 32, 48, 100) == -22        # misaligned
+    nb = ctypes.c_int(0)
+    assert L.rsu_update_table_finish(host, 1, ctypes.byref(nb)) == 0 and nb.value == 1
+
+
 def test_input_size_needed_abi_and_python(golden):
     from road_segmentation_unet_amd import _lib, input_size_needed
     L = _lib.lib()
