@@ -133,6 +133,63 @@ __global__ void k_maxpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// gradient junction at an encoder output, the training path (code bytes, whole windows, a pooled gradient): one thread = 8 channels
+// of one 2x2 window, blockIdx.y = (image, window row), so the index arithmetic is one multiply-high per thread (the general kernel
+// below spends ~500 vector instructions per thread on 64-bit divisions and builds float stand-ins of the activation from the code:
+// it runs at the vector ALU's pace, 4.6 TB/s alone on the chip and half of that beside a weight-gradient kernel). Same arithmetic:
+// dz[k] = (bit k of the code) ? dskip[k] + (k == first maximum ? dpool : 0) : 0, the sum in fp32, rounded once.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pool_skip_relu_bwd_code(const unsigned char* __restrict__ code, const bf16_t* __restrict__ dpool,
+                                                                 const bf16_t* __restrict__ dskip, bf16_t* __restrict__ dz, int N, int H, int W,
+                                                                 int C, int Hs, int Ws, unsigned ncg, unsigned ncg_magic, float keep, unsigned key) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const unsigned x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= (unsigned)Wp * ncg) return;
+    unsigned wx = __umulhi(x, ncg_magic), cg = x - wx * ncg;   // floor(2^32 / ncg) may fall one short
+    if (cg >= ncg) { ++wx; cg -= ncg; }
+    const int oy0 = (H - Hs) / 2, ox0 = (W - Ws) / 2;
+  for (int row = (int)blockIdx.y; row < N * Hp; row += (int)gridDim.y) {
+    const int n = row / Hp, wy = row - n * Hp;
+    const unsigned pidx = (unsigned)(((n * Hp + wy) * Wp + (int)wx) * C) + cg * 8;
+    const uint2 c2 = *(const uint2*)(code + pidx);
+    const u32x4 dp4 = *(const u32x4*)(dpool + pidx);
+    u32x4 g4[4];
+    bool have[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int sy = 2 * wy + (k >> 1) - oy0, sx = 2 * (int)wx + (k & 1) - ox0;
+        have[k] = dskip && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+        g4[k] = have[k] ? *(const u32x4*)(dskip + ((long)(n * Hs + sy) * Ws + sx) * C + cg * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float dp[8];
+    unpack8(dp4, dp);
+    if (keep < 1.f) {  // the pooled tensor went through dropout: same mask, same scale
+        const float inv = 1.f / keep;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dp[i] *= drop_keep(key, pidx + i, keep) * inv;
+    }
+    unsigned best[8], bits[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned byte = ((i < 4 ? c2.x : c2.y) >> (8 * (i & 3))) & 0xffu;
+        best[i] = byte >> 4;
+        bits[i] = byte;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g[8];
+        unpack8(g4[k], g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = g[i] + (best[i] == (unsigned)k ? dp[i] : 0.f);
+            g[i] = (bits[i] >> k) & 1u ? v : 0.f;
+        }
+        *(u32x4*)(dz + ((long)(n * H + 2 * wy + (k >> 1)) * W + 2 * (int)wx + (k & 1)) * C + cg * 8) = pack8(g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // gradient junction at an encoder output: MaxPoolGrad + zero-padded skip gradient + ReluGrad.
 // One thread = 8 channels of one 2x2 window.
 // ---------------------------------------------------------------------------------------------
@@ -376,56 +433,67 @@ __global__ void __launch_bounds__(256) k_head(const bf16_t* __restrict__ act, co
 #pragma unroll
     for (int i = 0; i < 8; ++i) gw0[i] = gw1[i] = 0.f;
     const long niter = (npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
-    for (long it = 0; it < niter; ++it) {
-        const long p = (it * gridDim.x + blockIdx.x) * ppb + threadIdx.x / LP;
-        const bool ok = p < npix;
-        float a[8];
-        if (ok) {
-            unpack8(*(const u32x4*)(act + p * C + sub * 8), a);
-        } else {
+    // two pixels per thread and trip, both loads requested before either is used: at 90 registers the kernel holds 5 waves per SIMD, and
+    // one 16-byte load per lane in flight is half of what the HBM latency needs (the sums keep the order of the pixels: same bits)
+    for (long it0 = 0; it0 < niter; it0 += 2) {
+        long pp[2];
+        bool okk[2];
+        u32x4 raw[2];
+        int labv[2] = {0, 0};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = 0.f;
+        for (int u = 0; u < 2; ++u) {
+            pp[u] = ((it0 + u) * gridDim.x + blockIdx.x) * ppb + threadIdx.x / LP;
+            okk[u] = (it0 + u < niter) && pp[u] < npix;
+            raw[u] = okk[u] ? *(const u32x4*)(act + pp[u] * C + sub * 8) : u32x4{0u, 0u, 0u, 0u};
+            if (TRAIN) labv[u] = okk[u] ? (int)labels[pp[u]] : 0;
         }
-        float l0 = 0.f, l1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            l0 = fmaf(a[i], w0[i], l0);
-            l1 = fmaf(a[i], w1[i], l1);
-        }
-        for (int o = 1; o < LP; o <<= 1) {
-            l0 += __shfl_xor(l0, o);
-            l1 += __shfl_xor(l1, o);
-        }
-        l0 += b0;
-        l1 += b1;
-        const float m = fmaxf(l0, l1);
-        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-        const float s = e0 + e1;
-        const float p1 = e1 / s, p0 = e0 / s;
-        if (ok && sub == 0) {
-            prob[p] = p1;
-            if (logits) {
-                logits[2 * p] = l0;
-                logits[2 * p + 1] = l1;
+        for (int u = 0; u < 2; ++u) {
+            const long p = pp[u];
+            const bool ok = okk[u];
+            float a[8];
+            unpack8(raw[u], a);
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                l0 = fmaf(a[i], w0[i], l0);
+                l1 = fmaf(a[i], w1[i], l1);
             }
-        }
-        if (TRAIN) {
-            if (ok) {
-                const int lab = (int)labels[p];
-                const float d0 = (p0 - (lab == 0 ? 1.f : 0.f)) * inv_count;
-                const float d1 = (p1 - (lab == 1 ? 1.f : 0.f)) * inv_count;
-                float da[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    gw0[i] = fmaf(a[i], d0, gw0[i]);
-                    gw1[i] = fmaf(a[i], d1, gw1[i]);
-                    da[i] = a[i] > 0.f ? fmaf(d0, w0[i], d1 * w1[i]) : 0.f;
+            for (int o = 1; o < LP; o <<= 1) {
+                l0 += __shfl_xor(l0, o);
+                l1 += __shfl_xor(l1, o);
+            }
+            l0 += b0;
+            l1 += b1;
+            const float m = fmaxf(l0, l1);
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            const float s = e0 + e1;
+            const float p1 = e1 / s, p0 = e0 / s;
+            if (ok && sub == 0) {
+                prob[p] = p1;
+                if (logits) {
+                    logits[2 * p] = l0;
+                    logits[2 * p + 1] = l1;
                 }
-                *(u32x4*)(dact + p * C + sub * 8) = pack8(da);
-                if (sub == 0) {
-                    gb0 += d0;
-                    gb1 += d1;
-                    lsum += -((lab ? l1 : l0) - m - logf(s));
+            }
+            if (TRAIN) {
+                if (ok) {
+                    const int lab = labv[u];
+                    const float d0 = (p0 - (lab == 0 ? 1.f : 0.f)) * inv_count;
+                    const float d1 = (p1 - (lab == 1 ? 1.f : 0.f)) * inv_count;
+                    float da[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        gw0[i] = fmaf(a[i], d0, gw0[i]);
+                        gw1[i] = fmaf(a[i], d1, gw1[i]);
+                        da[i] = a[i] > 0.f ? fmaf(d0, w0[i], d1 * w1[i]) : 0.f;
+                    }
+                    *(u32x4*)(dact + p * C + sub * 8) = pack8(da);
+                    if (sub == 0) {
+                        gb0 += d0;
+                        gb1 += d1;
+                        lsum += -((lab ? l1 : l0) - m - logf(s));
+                    }
                 }
             }
         }
@@ -764,6 +832,14 @@ hipError_t ew_maxpool_fwd(const void* x, void* y, void* code, int N, int H, int 
 }
 hipError_t ew_pool_skip_relu_bwd(const void* yact, const void* code, const void* dpool, const void* dskip, void* dz, int N, int H, int W, int C,
                                  int Hs, int Ws, float keep, unsigned key, hipStream_t st) {
+    if (code && dpool && !((H | W) & 1) && (long)N * H * W * C < (1l << 31)) {   // whole windows, a code byte per pooled element: the lean kernel
+        const unsigned ncg = (unsigned)(C / 8), per_row = (unsigned)(W / 2) * ncg;
+        const long rows = (long)N * (H / 2);
+        hipLaunchKernelGGL(k_pool_skip_relu_bwd_code, dim3((per_row + 255) / 256, (unsigned)(rows < 32768 ? rows : 32768)), dim3(256), 0, st,
+                           (const unsigned char*)code, (const bf16_t*)dpool, (const bf16_t*)dskip, (bf16_t*)dz, N, H, W, C, dskip ? Hs : 0, dskip ? Ws : 0, ncg,
+                           ncg == 1 ? 0xffffffffu : (unsigned)(0x100000000ull / ncg), keep, key);
+        return hipGetLastError();
+    }
     const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(k_pool_skip_relu_bwd, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)yact, (const unsigned char*)code,
                        (const bf16_t*)dpool,

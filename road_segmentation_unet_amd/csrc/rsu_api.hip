@@ -706,6 +706,13 @@ extern "C" int rsu_conv_first_fwd(const void* in16, const void* packed, const fl
     rsu_src_t s;
     s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
     const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    if (env_int("RSU_FIRST_GEN", 1) != 0) {   // (0: the layer as a launch of the generic implicit-GEMM kernels, as in rounds 1-3a)
+        const int n = launch_ncu(ncu);
+        if (n < 0) return RSU_EINVAL;
+        if ((long)N * Ho * Wo * Cout * 2 >= 0x7ffffff0L || (long)N * H * W * 32 >= 0x7ffffff0L) return RSU_E2BIG;
+        HIP_CHECK_RET(conv_first_fwd_launch(in16, packed, rup(Cout, 128) / 16, b, y, N, H, W, Cout, dil, 1, n, (hipStream_t)stream));
+        return RSU_OK;
+    }
     return run_fwd(&s, 1, packed, 0, rup(Cout, 128) / 16, 0, b, y, nullptr, N, H, W, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0, Ho, Wo, 1, 1, 1, 0,
                    ncu, (hipStream_t)stream);
 }

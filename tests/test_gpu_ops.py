@@ -375,6 +375,32 @@ def test_color_adjust_and_first_conv(dil, keep):
     hu.assert_f32_close(hu.host(gx), ref_gx, "conv_first gx")
 
 
+@pytest.mark.parametrize("N,H,W,Cout,dil", [(2, 200, 203, 64, 1), (1, 40, 37, 16, 2), (3, 21, 50, 72, 1), (1, 64, 64, 160, 2), (1, 5, 19, 8, 1)])
+def test_first_conv_kernel_against_oracle_and_generic_launch(N, H, W, Cout, dil, monkeypatch):
+    """k_conv_first_fwd (weights in registers, pixels straight from global memory; the default of rsu_conv_first_fwd) against the oracle and
+    against the same layer as a launch of the generic implicit-GEMM kernels (RSU_FIRST_GEN=0): more pieces than waves, ragged row ends,
+    channel counts that are not multiples of 64, both dilations. The two kernels sum the 9 x 16 products in another order: equal
+    to one bf16 rounding step."""
+    rng = np.random.RandomState(H + Cout)
+    in16 = hu.q(_rand(rng, N, H, W, 16))
+    w1 = _rand(rng, 3, 3, 3, Cout, scale=0.3)
+    b1 = _rand(rng, Cout, scale=0.1)
+    ind, w1d, b1d = hu.dev_bf16(in16), hu.dev_f32(w1), hu.dev_f32(b1)
+    pk1 = torch.zeros(lib().rsu_packed_first_bytes(Cout) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_pack_conv_first", hu.ptr(w1d), hu.ptr(pk1), Cout, hu.stream())
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    out = {}
+    for gen in ("1", "0"):
+        monkeypatch.setenv("RSU_FIRST_GEN", gen)
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        call("rsu_conv_first_fwd", hu.ptr(ind), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(y), N, H, W, Cout, dil, 0, hu.stream())
+        out[gen] = hu.host(y)
+        hu.assert_bf16_close(out[gen], U.conv2d_fwd(in16[..., 0:3], hu.q(w1), b1, dil=dil), "conv_first_fwd gen " + gen)
+    d = np.abs(out["1"].astype(np.float64) - out["0"].astype(np.float64))
+    assert d.max() <= 2.0 ** -7 * max(1.0, np.abs(out["0"]).max()), d.max()
+    assert (d > 0).mean() < 0.01
+
+
 # ------------------------------------------------------------------------------------------- pool
 @pytest.mark.parametrize("Cout,scale", [(64, 1.0), (16, 1.25), (72, 1.0)])
 def test_color_adjust_bwd_from_scatter_buffer(Cout, scale):

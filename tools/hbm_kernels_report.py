@@ -25,7 +25,9 @@ n_param = 31031822
 npix_out, npix_in = B * P * P, B * S * S
 alg = {  # kernel-name prefix -> (what, bytes per step)
     "_Z13k_maxpool_fwd": ("2x2 max-pool fwd (+dropout) + code byte, levels %s: 2 B read + 0.5 B + 0.25 B written per input element" % pool_levels, 2.75 * n_pool_kernel),
-    "_Z20k_pool_skip_relu_bwd": ("pool bwd + skip-gradient add + ReLU mask from the code bytes: 0.25 B code + 0.5 B dpool + ~1 B dskip (the "
+    "_Z16k_conv_first_fwd": ("first 3x3 conv forward (16-channel input straight from global memory, weights in registers): 32 B read per input "
+                             "pixel, 128 B written per output pixel", 32.0 * npix_in + 128.0 * B * (S - 2) ** 2),
+    "_Z25k_pool_skip_relu_bwd_code": ("pool bwd + skip-gradient add + ReLU mask from the code bytes: 0.25 B code + 0.5 B dpool + ~1 B dskip (the "
                                  "cropped window) read, 2 B dz written per input element", 3.8 * n_pool_in),
     "_Z18k_update_pack_many": ("Momentum step + re-pack in one pass: w, a, g read, w, a written, both bf16 packed layouts written (24 B per weight)", 24.0 * n_param),
     "_Z6k_head": ("1x1 head + softmax + CE + gradients: 128 B read + 128 B written per output pixel", 256.0 * npix_out),
