@@ -381,8 +381,11 @@ __global__ void __launch_bounds__(256) k_reduce_slabs_wide(const float* __restri
 // orders as the single launches
 __global__ void __launch_bounds__(256) k_reduce_slabs_many(const ReduceJob* __restrict__ jobs, int njobs) {
     __shared__ f32x4 red[256];
-    int r = 0;
-    while (r + 1 < njobs && (int)blockIdx.x >= jobs[r + 1].block_begin) ++r;
+    // (njobs <= 16 <= 64 lanes: every lane tests one job, a ballot counts those that begin at or before this block -- one L2 round trip
+    // instead of up to 16 dependent ones)
+    const int lj = threadIdx.x & 63;
+    const bool mine = lj < njobs && jobs[lj].block_begin <= (int)blockIdx.x;
+    const int r = __popcll(__ballot(mine)) - 1;
     const ReduceJob J = jobs[r];
     const int b = blockIdx.x - J.block_begin;
     const long total = (long)J.ntap * J.cs_cnt * (J.CfOut >> 2);
@@ -528,23 +531,19 @@ template __global__ void k_head<false>(const bf16_t*, const float*, const float*
 
 __global__ void __launch_bounds__(256) k_head_final(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ db,
                                                     float* __restrict__ loss_sum, int nblk, int C) {
-    // 8 outputs x 32 partial lanes per block (a lane walks nblk/32 partials: short dependent chains), fixed-order LDS tree
-    __shared__ float red[256];
+    // one wave per output (four per workgroup): lane l sums partials l, l + 64, ... (independent loads), then a fixed-order butterfly;
+    // 2 C + 3 outputs of ~1000 partials each -- with 32 lanes per output in 17 workgroups the kernel was a chain of ~32 dependent
+    // L2 round trips (11 us)
     const int nout = 2 * C + 3;
-    const int ol = threadIdx.x & 7, part = threadIdx.x >> 3;
-    const int o = blockIdx.x * 8 + ol;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= nout) return;
     float t = 0.f;
-    if (o < nout)
-        for (int bk = part; bk < nblk; bk += 32) t += partial[(long)bk * nout + o];
-    red[threadIdx.x] = t;
-    __syncthreads();
-    if (part == 0 && o < nout) {
-        float r = 0.f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) r += red[q * 8 + ol];
-        if (o < 2 * C) dw[o] = r;
-        else if (o < 2 * C + 2) db[o - 2 * C] = r;
-        else loss_sum[0] += r;
+    for (int bk = lane; bk < nblk; bk += 64) t += partial[(long)bk * nout + o];
+    for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m);
+    if (lane == 0) {
+        if (o < 2 * C) dw[o] = t;
+        else if (o < 2 * C + 2) db[o - 2 * C] = t;
+        else loss_sum[0] += t;
     }
 }
 
@@ -891,7 +890,7 @@ hipError_t ew_head(bool train, const void* act, const float* w, const float* b, 
     const int nb = ew_head_blocks(npix, C);
     if (train) {
         hipLaunchKernelGGL(k_head<true>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, labels, prob, logits, (bf16_t*)dact, ws, npix, C, inv_count);
-        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 7) / 8), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
+        hipLaunchKernelGGL(k_head_final, dim3((2 * C + 3 + 3) / 4), dim3(256), 0, st, ws, dw, db, loss_sum, nb, C);
     } else {
         hipLaunchKernelGGL(k_head<false>, dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, nullptr, prob, logits, nullptr, nullptr, npix, C, 0.f);
     }
@@ -934,13 +933,13 @@ hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hi
 __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restrict__ jobs, int njobs, float lr, float mu, float gscale) {
     __shared__ int sj;
     __shared__ float tile[4][32][33];
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = njobs - 1;
-        while (lo < hi) {  // last job whose block_start <= blockIdx.x
-            const int mid = (lo + hi + 1) >> 1;
-            if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-        }
-        sj = lo;
+    if (threadIdx.x < 64) {
+        // last job whose block_start <= blockIdx.x = (number of such jobs) - 1 (block_start ascends): every lane tests its share, ONE round
+        // trip to L2 instead of the seven dependent ones of a binary search by lane 0 (a third of a workgroup's short life)
+        int cnt = 0;
+        for (int j = threadIdx.x; j < njobs; j += 64) cnt += jobs[j].block_start <= (int)blockIdx.x ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (threadIdx.x == 0) sj = cnt - 1;
     }
     __syncthreads();
     const UpJob& J = jobs[sj];
