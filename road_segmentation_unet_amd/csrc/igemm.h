@@ -114,6 +114,13 @@ int igemm_wgrad_csb(int cfg);  // S channels per workgroup (grid.y block)
 int igemm_wgrad_kgroups(int cfg);  // slabs written per grid.z slice
 hipError_t igemm_wgrad_launch(int cfg, int ntap, const IgWgradParams& p, int grid_x, int grid_y, int grid_z,
                               hipStream_t st);
+// igemm_wgt.hip: weight gradient + bias gradient of the 2x2 stride-2 transposed conv as a ping-pong kernel (slabs as igemm_wgrad's:
+// [4][Cout][Cin] + a row of rup(Cout, 4) bias sums per pixel split; one split writes dK / db in place)
+bool igemm_wgt_supports(int N, int H, int W, int Cin, int Cout);
+int igemm_wgt_blocks(int Cin, int Cout);   // workgroups per pixel split
+int igemm_wgt_tiles(int N, int H, int W);  // 64-pixel tiles of the reduction
+hipError_t igemm_wgt_launch(const void* x, const void* dy, float* slab, float* sbslab, long slab_stride, int N, int H, int W, int Cin, int Cout,
+                            int nsplit, hipStream_t st);
 // the grouped launch (igemm_wgpp.hip, igemm_wg_group_kernel): up to IGW_GROUP_MAX layers' weight gradients in one launch
 enum { IGW_FAM_WGPP3 = 0, IGW_FAM_WGPP4 = 1, IGW_FAM_WGPP5 = 2, IGW_FAM_WGPP6 = 3, IGW_FAM_WGP64_4 = 4, IGW_FAM_WGP64_5 = 5,
        IGW_FAM_GENERIC = 8 /* + 2 * cfg + (ntap == 4) */ };

@@ -934,6 +934,23 @@ extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
 extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W, int Cin,
                                        int Cout, int ncu, rsu_stream_t stream) {
     if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
+    // RSU_WGT_GEN=1: the generic igemm_wgrad launch (4 taps, stride 2) of rounds 1-3a; 3: the ping-pong kernel of igemm_wgt.hip; 2 (default):
+    // the ping-pong kernel where the launch has (most of) the chip to itself. Beside a backward-data kernel on the other half of the chip
+    // the faster kernel made the STEP slower (945 -> 938 patches/s, profiles/r03/lib_ab_wgt.txt): the weight-gradient stream has slack
+    // there, the backward-data chain is the critical path, and a side kernel that draws more HBM bandwidth and power only slows that chain.
+    const int wgt_gen = env_int("RSU_WGT_GEN", 2);
+    if (wgt_gen >= 2 && igemm_wgt_supports(N, H, W, Cin, Cout) && (wgt_gen >= 3 || launch_ncu(ncu) >= 192)) {
+        const int n = launch_ncu(ncu);
+        if (n < 0) return RSU_EINVAL;
+        const int ntiles = igemm_wgt_tiles(N, H, W);
+        int nsplit = n / igemm_wgt_blocks(Cin, Cout);   // one workgroup per budgeted CU (the workspace holds the splits of a whole chip)
+        nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+        const long main_elems = 4l * Cout * Cin, extra = db ? rup(Cout, 4) : 0, stride = main_elems + extra;
+        HIP_CHECK_RET(igemm_wgt_launch(x, dy, nsplit == 1 ? dK : ws, db ? (nsplit == 1 ? db : ws + main_elems) : nullptr, stride, N, H, W, Cin, Cout,
+                                       nsplit, (hipStream_t)stream));
+        if (nsplit > 1) HIP_CHECK_RET(ew_reduce_slabs(ws, dK, db, (int)(extra / 4), nsplit, stride, 4, Cout, 0, Cout, Cin, (hipStream_t)stream));
+        return RSU_OK;
+    }
     rsu_src_t s;
     s.ptr = dy; s.H = 2 * H; s.W = 2 * W; s.C = Cout; s.oy = 0; s.ox = 0;
     // F = x (cf = ci), S = dy (cs = co), stride 2: slab[tap(a,b)][co][ci] = K layout

@@ -506,6 +506,38 @@ def test_convT(N, H, W, Cin, Cout):
     hu.assert_f32_close(hu.host(dbT), rdb, "convT bias grad fused in bwd_weight")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(4, 100, 100, 256, 128), (1, 7, 9, 128, 64), (2, 33, 31, 72, 96), (3, 28, 28, 1024, 512), (1, 61, 67, 64, 32),
+                                            (2, 50, 52, 200, 160)])
+@pytest.mark.parametrize("ncu", [0, 128, 64])
+def test_convT_weight_gradient_pingpong_against_generic_launch(N, H, W, Cin, Cout, ncu, monkeypatch):
+    """igemm_wgt (RSU_WGT_GEN=3: phase images of dy, ping-pong over the k-steps, flat 64-pixel tiles) against the generic 4-tap stride-2
+    igemm_wgrad launch (RSU_WGT_GEN=1) and the oracle: many tiles per workgroup, a single tile (one split: written in place), pixel
+    counts that are not multiples of 64, channel blocks that are not full, every CU budget the schedules use. The two kernels sum the
+    pixels in another order: equal to fp32 summation noise; each is repeatable bit for bit."""
+    rng = np.random.RandomState(H + Cin)
+    x = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
+    dy = hu.q(_rand(rng, N, 2 * H, 2 * W, Cout, scale=0.1))
+    xd, dyd = hu.dev_bf16(x), hu.dev_bf16(dy)
+    ws = torch.zeros(lib().rsu_convT2x2_bwd_weight_ws_floats(Cin, Cout), dtype=torch.float32, device=hu.DEV)
+    out = {}
+    for gen in ("3", "1", "3"):
+        monkeypatch.setenv("RSU_WGT_GEN", gen)
+        dK = torch.full((2, 2, Cout, Cin), float("nan"), dtype=torch.float32, device=hu.DEV)
+        db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+        ws.fill_(float("nan"))
+        call("rsu_convT2x2_bwd_weight", hu.ptr(xd), hu.ptr(dyd), hu.ptr(dK), hu.ptr(db), hu.ptr(ws), N, H, W, Cin, Cout, ncu, hu.stream())
+        if gen in out:
+            assert torch.equal(dK, out[gen][0]) and torch.equal(db, out[gen][1]), "the ping-pong kernel must repeat bit for bit"
+        out[gen] = (dK, db)
+    if N * H * W * Cin * Cout <= 3e9:   # (the oracle's loops: seconds)
+        rdK, rdb = U.convT_bwd(x, np.zeros((2, 2, Cout, Cin), np.float32), dy)[1:]
+        hu.assert_f32_close(hu.host(out["3"][0]), rdK, "convT bwd_weight (ping-pong)")
+        hu.assert_f32_close(hu.host(out["3"][1]), rdb, "convT bias grad (ping-pong)")
+    for a, b in zip(out["3"], out["1"]):
+        a, b = hu.host(a).astype(np.float64), hu.host(b).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
 # ------------------------------------------------------------------------------------------- head, optimizer
 @pytest.mark.parametrize("C", [64, 16])
 def test_head(C):
