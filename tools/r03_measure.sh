@@ -41,9 +41,9 @@ if dbs:
             w.writerow([n, c, t, "%.1f" % a, "%.2f" % (100.0 * t / tot), mn, mx])
     fam = collections.OrderedDict()
     def family(n):
-        for k, lab in (("igemm_wg_group", "igemm_wg_group (3x3 + convT weight gradients, grouped)"), ("igemm_pp_kernel", "igemm_pp (3x3 fwd / bwd-data)"),
+        for k, lab in (("igemm_wg_group", "igemm_wg_group (3x3 weight gradients, grouped)"), ("igemm_pp_kernel", "igemm_pp (3x3 fwd / bwd-data)"),
                        ("igemm_fwd2_kernel", "igemm_fwd2 (3x3: level-0 conv1, five-fragment shapes)"), ("igemm_wgpp", "igemm_wgpp"), ("igemm_wgp64", "igemm_wgp64"),
-                       ("igemm_wgrad_kernel", "igemm_wgrad (level-0 conv1 / ungrouped)"), ("igemm_ct", "igemm_ct (convT fwd / bwd-data)"),
+                       ("igemm_wgt_kernel", "igemm_wgt (convT weight gradients)"), ("igemm_wgrad_kernel", "igemm_wgrad (level-0 conv1 / ungrouped)"), ("igemm_ct", "igemm_ct (convT fwd / bwd-data)"),
                        ("k_reduce_slabs", "k_reduce_slabs*")):
             if k in n: return lab
         return n.split("(")[0][:40]
@@ -73,7 +73,7 @@ def conv3(k):
 def wg(k):
     return "wgrad" in k or "wgpp" in k or "wgp64" in k or "wg_group" in k
 fams = {"igemm_pp + igemm_fwd2 3x3 (forward, backward-data)": lambda k: conv3(k) and not wg(k),
-        "weight gradient launches (igemm_wg_group: all 3x3 layers + the transposed convs of a step in 2 launches; level-0 conv1)": lambda k: conv3(k) and wg(k),
+        "weight gradient launches (igemm_wg_group: all 3x3 layers of a step in 2 launches; level-0 conv1)": lambda k: conv3(k) and wg(k),
         "k_reduce_slabs*": lambda k: "k_reduce_slabs" in k, "conv3x3 all": conv3}
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over python3 bench.py --steps 3 --warmup 1, single-stream schedule, "
                  "tile shapes of the bench run imported (tools/r03_measure.sh); raw counter unit KiB; gfx950: FETCH_SIZE x 2 for 16-byte-per-lane reads",
