@@ -936,8 +936,8 @@ extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK,
     if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
     // RSU_WGT_GEN=1: the generic igemm_wgrad launch (4 taps, stride 2) of rounds 1-3a; 3: the ping-pong kernel of igemm_wgt.hip; 2 (default):
     // the ping-pong kernel where the launch has (most of) the chip to itself. Beside a backward-data kernel on the other half of the chip
-    // the faster kernel made the STEP slower (945 -> 938 patches/s, profiles/r03/lib_ab_wgt.txt): the weight-gradient stream has slack
-    // there, the backward-data chain is the critical path, and a side kernel that draws more HBM bandwidth and power only slows that chain.
+    // the faster kernel made the STEP slower, reproducibly (945 -> 938 patches/s, profiles/r03/lib_ab_wgt.txt, split_sweep_wgt.txt; DESIGN.md
+    // section 3.7 lists what was tried around it).
     const int wgt_gen = env_int("RSU_WGT_GEN", 2);
     if (wgt_gen >= 2 && igemm_wgt_supports(N, H, W, Cin, Cout) && (wgt_gen >= 3 || launch_ncu(ncu) >= 192)) {
         const int n = launch_ncu(ncu);
