@@ -121,6 +121,13 @@ int igemm_wgt_blocks(int Cin, int Cout);   // workgroups per pixel split
 int igemm_wgt_tiles(int N, int H, int W);  // 64-pixel tiles of the reduction
 hipError_t igemm_wgt_launch(const void* x, const void* dy, float* slab, float* sbslab, long slab_stride, int N, int H, int W, int Cin, int Cout,
                             int nsplit, hipStream_t st);
+// igemm_wg1.hip: weight gradient + bias gradient of the first 3x3 conv (16-channel input) as a ping-pong kernel over phase images of in16
+// (slabs as igemm_wgrad's 64x16 launch: [9][16][Cout] + a bias row of Cout floats per pixel split)
+bool igemm_wg1_supports(int N, int H, int W, int Cout, int dil);
+int igemm_wg1_blocks(int Cout);
+int igemm_wg1_tiles(int N, int Ho, int Wo);
+hipError_t igemm_wg1_launch(const void* in16, const void* dz, float* slab, float* bslab, long slab_stride, int N, int H, int W, int Cout, int dil,
+                            int nsplit, hipStream_t st);
 // the grouped launch (igemm_wgpp.hip, igemm_wg_group_kernel): up to IGW_GROUP_MAX layers' weight gradients in one launch
 enum { IGW_FAM_WGPP3 = 0, IGW_FAM_WGPP4 = 1, IGW_FAM_WGPP5 = 2, IGW_FAM_WGPP6 = 3, IGW_FAM_WGP64_4 = 4, IGW_FAM_WGP64_5 = 5,
        IGW_FAM_GENERIC = 8 /* + 2 * cfg + (ntap == 4) */ };

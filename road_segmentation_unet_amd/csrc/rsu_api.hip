@@ -967,6 +967,20 @@ extern "C" int rsu_conv_first_bwd_weight(const void* in16, const void* dz, float
     s.ptr = in16; s.H = H; s.W = W; s.C = 16; s.oy = 0; s.ox = 0;
     float* tmp = ws;                          // [9][16][Cout]
     float* slabs = ws + (size_t)9 * 16 * Cout;
+    // RSU_WG1_GEN=1: the generic igemm_wgrad launch (64x16 shape) of rounds 1-3a; default: the ping-pong kernel of igemm_wg1.hip
+    if (env_int("RSU_WG1_GEN", 2) >= 2 && igemm_wg1_supports(N, H, W, Cout, dil)) {
+        const int n = launch_ncu(ncu);
+        if (n < 0) return RSU_EINVAL;
+        const int ntiles = igemm_wg1_tiles(N, H - 2 * dil, W - 2 * dil);
+        int nsplit = n / igemm_wg1_blocks(Cout);
+        nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+        const long main_elems = 9l * 16 * Cout, extra = db ? Cout : 0, stride = main_elems + extra;
+        HIP_CHECK_RET(igemm_wg1_launch(in16, dz, nsplit == 1 ? tmp : slabs, db ? (nsplit == 1 ? db : slabs + main_elems) : nullptr, stride, N, H, W, Cout,
+                                       dil, nsplit, (hipStream_t)stream));
+        if (nsplit > 1) HIP_CHECK_RET(ew_reduce_slabs(slabs, tmp, db, (int)(extra / 4), nsplit, stride, 9, 16, 0, 16, Cout, (hipStream_t)stream));
+        HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));
+        return RSU_OK;
+    }
     int rc = run_wgrad(IGW_CFG_64x16, dz, H - 2 * dil, W - 2 * dil, Cout, &s, tmp, slabs, 16, Cout, 0, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db);
     if (rc) return rc;
     HIP_CHECK_RET(ew_scatter_first_grads(tmp, dw1, gxc, Cout, (hipStream_t)stream));

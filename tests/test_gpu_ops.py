@@ -401,6 +401,40 @@ def test_first_conv_kernel_against_oracle_and_generic_launch(N, H, W, Cout, dil,
     assert (d > 0).mean() < 0.01
 
 
+@pytest.mark.parametrize("N,H,W,Cout,dil", [(2, 200, 203, 64, 1), (1, 40, 37, 16, 2), (3, 21, 50, 72, 1), (1, 64, 64, 160, 2), (1, 5, 19, 8, 1),
+                                            (4, 130, 126, 64, 1)])
+@pytest.mark.parametrize("ncu", [0, 128, 32])
+def test_first_conv_weight_gradient_pingpong_against_generic_launch(N, H, W, Cout, dil, ncu, monkeypatch):
+    """igemm_wg1 (default of rsu_conv_first_bwd_weight: nine phase images of in16, every wave holds the whole 64 x 16 x 9 block, the
+    groups alternate tiles) against the generic 64x16 igemm_wgrad launch (RSU_WG1_GEN=1) and the oracle: one tile per workgroup and
+    dozens (CU budget 32), pixel counts that are not multiples of 128, channel blocks that are not full, both dilations. Another
+    summation order: equal to fp32 noise; repeatable bit for bit."""
+    rng = np.random.RandomState(H + Cout)
+    in16 = hu.q(_rand(rng, N, H, W, 16))
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    dz = hu.q(_rand(rng, N, Ho, Wo, Cout, scale=0.1))
+    ind, dzd = hu.dev_bf16(in16), hu.dev_bf16(dz)
+    ws = torch.zeros(lib().rsu_conv_first_bwd_ws_floats(Cout), dtype=torch.float32, device=hu.DEV)
+    out = {}
+    for gen in ("2", "1", "2"):
+        monkeypatch.setenv("RSU_WG1_GEN", gen)
+        dw1 = torch.full((3, 3, 3, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+        gx = torch.full((9, 12, Cout), float("nan"), dtype=torch.float32, device=hu.DEV)
+        db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=hu.DEV)
+        ws.fill_(float("nan"))
+        call("rsu_conv_first_bwd_weight", hu.ptr(ind), hu.ptr(dzd), hu.ptr(dw1), hu.ptr(gx), hu.ptr(db), hu.ptr(ws), N, H, W, Cout, dil, ncu, hu.stream())
+        if gen in out:
+            for a, b in zip((dw1, gx, db), out[gen]):
+                assert torch.equal(a, b), "the ping-pong kernel must repeat bit for bit"
+        out[gen] = (dw1, gx, db)
+    hu.assert_f32_close(hu.host(out["2"][2]), dz.reshape(-1, Cout).astype(np.float64).sum(0), "conv_first db (ping-pong)")
+    hu.assert_f32_close(hu.host(out["2"][0]), U.conv2d_bwd_weight(in16[..., 0:3], dz, dil=dil)[0], "conv_first dW (ping-pong)")
+    hu.assert_f32_close(hu.host(out["2"][1]), U.conv2d_bwd_weight(in16[..., 4:16], dz, dil=dil)[0].reshape(9, 12, Cout), "conv_first gx (ping-pong)")
+    for a, b in zip(out["2"], out["1"]):
+        a, b = hu.host(a).astype(np.float64), hu.host(b).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
 # ------------------------------------------------------------------------------------------- pool
 @pytest.mark.parametrize("Cout,scale", [(64, 1.0), (16, 1.25), (72, 1.0)])
 def test_color_adjust_bwd_from_scatter_buffer(Cout, scale):

@@ -18,7 +18,7 @@ db = sqlite3.connect(glob.glob("/tmp/kab/**/*.db", recursive=True)[0]); cur = db
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if "kernel_dispatch" in t][0]; ks = [t for t in tabs if "kernel_symbol" in t][0]
 for n, c, a in cur.execute(f"select s.kernel_name, count(*), avg(d.end-d.start) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc"):
-    if ("igemm" in n and "igemm_fwd2" not in n) or "at::" in n or "rocclr" in n: continue
+    if ("igemm" in n and "igemm_fwd2" not in n and "igemm_wg1" not in n and "igemm_wgrad_kernel" not in n and "igemm_wgt" not in n) or "at::" in n or "rocclr" in n: continue
     print("   %-60s calls %4d  avg %7.1f us  total %8.1f us" % (n.split("(")[0][:60], c, a / 1e3, a * c / 1e3))
 PY
 done > $OUT/kernel_ab_$NAME.txt 2>&1
