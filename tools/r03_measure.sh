@@ -69,11 +69,11 @@ def agg(pat, name):
     return d
 rd, wr = agg("rd", "FETCH_SIZE"), agg("wr", "WRITE_SIZE")
 def conv3(k):
-    return "igemm_pp_kernel" in k or "igemm_wgpp_kernel" in k or "igemm_wgp64_kernel" in k or "igemm_wg_group" in k or ("igemm_fwd2_kernel" in k and ", 9, 3," in k) or ("igemm_wgrad_kernel" in k and ", 9, 3," in k)
+    return "igemm_pp_kernel" in k or "igemm_wgpp_kernel" in k or "igemm_wgp64_kernel" in k or "igemm_wg_group" in k or ("igemm_fwd2_kernel" in k and ", 9, 3," in k) or ("igemm_wgrad_kernel" in k and ", 9, 3," in k) or "igemm_wg1_kernel" in k or "k_conv_first_fwd" in k
 def wg(k):
-    return "wgrad" in k or "wgpp" in k or "wgp64" in k or "wg_group" in k
-fams = {"igemm_pp + igemm_fwd2 3x3 (forward, backward-data)": lambda k: conv3(k) and not wg(k),
-        "weight gradient launches (igemm_wg_group: all 3x3 layers of a step in 2 launches; level-0 conv1)": lambda k: conv3(k) and wg(k),
+    return "wgrad" in k or "wgpp" in k or "wgp64" in k or "wg_group" in k or "igemm_wg1" in k
+fams = {"igemm_pp + igemm_fwd2 3x3 + k_conv_first_fwd (forward, backward-data)": lambda k: conv3(k) and not wg(k),
+        "weight gradient launches (igemm_wg_group: all 3x3 layers of a step in 2 launches; level-0 conv1 = igemm_wg1)": lambda k: conv3(k) and wg(k),
         "k_reduce_slabs*": lambda k: "k_reduce_slabs" in k, "conv3x3 all": conv3}
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) over python3 bench.py --steps 3 --warmup 1, single-stream schedule, "
                  "tile shapes of the bench run imported (tools/r03_measure.sh); raw counter unit KiB; gfx950: FETCH_SIZE x 2 for 16-byte-per-lane reads",
