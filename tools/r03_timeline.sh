@@ -24,7 +24,7 @@ i0, i1 = mom[-8], mom[-7]
 seg = rows[i0:i1]
 t0 = seg[0][1]
 def short(n):
-    for k in ("igemm_wg_group", "igemm_wgpp", "igemm_wgp64", "igemm_wgrad", "igemm_pp", "igemm_fwd2", "igemm_ct", "k_reduce_slabs_many", "k_reduce_slabs", "k_pool_skip", "k_maxpool", "k_head", "k_momentum", "k_pack", "k_color_adjust_bwd", "k_color_adjust", "k_scatter"):
+    for k in ("igemm_wg_group", "igemm_wgpp", "igemm_wgp64", "igemm_wgt", "igemm_wg1", "igemm_wgrad", "k_conv_first_fwd", "k_update_pack", "igemm_pp", "igemm_fwd2", "igemm_ct", "k_reduce_slabs_many", "k_reduce_slabs", "k_pool_skip", "k_maxpool", "k_head", "k_momentum", "k_pack", "k_color_adjust_bwd", "k_color_adjust", "k_scatter"):
         if k in n: return k
     return n[:30]
 with open("$OUT/timeline_g$G.txt", "w") as f:
