@@ -21,7 +21,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/pmcq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if "igemm" not in k: continue
+        if "igemm" not in k and "conv_first" not in k: continue
         cnt[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/pmc_step_kernels.csv", "w") as f:
     f.write("kernel,launches,us_under_pmc,MFMA_insts,nonMFMA_VALU_per_MFMA,SALU_per_MFMA,LDS_insts_per_MFMA,VMEM_insts_per_MFMA,WAIT_ANY_frac_of_wave_cycles,LDS_bank_conflict_frac,clock_GHz_GRBM,mfma_pipe_util_at_that_clock\n")
