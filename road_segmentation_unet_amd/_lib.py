@@ -153,3 +153,34 @@ def call(name, *args):
         torch.cuda.synchronize()
         return
     check(getattr(lib(), name)(*args), name)
+
+
+# ---- stream fork without a system-scope fence -------------------------------------------------------------------------------------
+_hip = None
+_fork_events = []
+_fork_next = 0
+
+
+def hip_fork(main_stream, side_stream):
+    """`side_stream` waits for everything issued on `main_stream` so far (both hipStream_t handles as integers), through a HIP event
+    created with hipEventDisableTiming | hipEventDisableSystemFence. torch.cuda.Event releases at system scope (visible to the host and
+    to other devices); a dependency between two streams of ONE device needs agent scope only, and the event's packet holds up the
+    recording queue for less (unet.UNet._Side: one fork per weight-gradient launch, +0.9 % on the step). A ring of 64 events is
+    re-used: an event is re-recorded long after its waiter has been enqueued (hipStreamWaitEvent captures the record in flight)."""
+    global _hip, _fork_next
+    if _hip is None:
+        h = ctypes.CDLL("libamdhip64.so")   # the runtime torch has already loaded
+        h.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        h.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        h.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        for _ in range(64):
+            ev = ctypes.c_void_p()
+            rc = h.hipEventCreateWithFlags(ctypes.byref(ev), 0x2 | 0x20000000)   # hipEventDisableTiming | hipEventDisableSystemFence
+            if rc != 0:
+                raise RsuError("hipEventCreateWithFlags failed (%d)" % rc)
+            _fork_events.append(ev)
+        _hip = h
+    ev = _fork_events[_fork_next]
+    _fork_next = (_fork_next + 1) % len(_fork_events)
+    if _hip.hipEventRecord(ev, ctypes.c_void_p(main_stream)) != 0 or _hip.hipStreamWaitEvent(ctypes.c_void_p(side_stream), ev, 0) != 0:
+        raise RsuError("hipEventRecord / hipStreamWaitEvent failed")

@@ -25,6 +25,8 @@ NUM_LABELS = 2    # src/constants.py:4
 # group, and the fine grain keeps both streams busy to the end -- measured, profiles/r03/wg_group_schedules.txt), ONE grouped launch behind
 # the pass where everything runs on one stream (alone on the chip a layer's launch pays 75 MB of slabs and a partly filled last round)
 _WG_GROUP_TWO_STREAMS, _WG_GROUP_ONE_STREAM = "0", "all"
+# RSU_RAW_EVENTS=0: fork the side stream through torch events (system-scope release) instead of _lib.hip_fork (agent scope)
+_RAW_EVENTS = os.environ.get("RSU_RAW_EVENTS", "1") != "0"
 _SPLIT_DEFAULT = "128,128"   # RSU_SPLIT_CHIP: CUs the main stream / each side stream plan for during the backward pass (UNet._Side)
 
 
@@ -409,10 +411,15 @@ class UNet:
             if n._split is not None:
                 n._ncu = n._split[0] if self.alone else n._split[2][k]
             ev = self.after
-            if ev is None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(n.device))
-            n.wstreams[k].wait_event(ev)
+            if ev is None and _RAW_EVENTS:
+                # the fork costs the MAIN queue an idle gap per weight-gradient launch (the event's packet sits between two backward-data
+                # kernels): ~6 us with a torch event, less without the system-scope fence a same-device dependency does not need
+                _lib.hip_fork(torch.cuda.current_stream(n.device).cuda_stream, n.wstreams[k].cuda_stream)
+            else:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(n.device))
+                n.wstreams[k].wait_event(ev)
             self.ctx = torch.cuda.stream(n.wstreams[k])
             self.ctx.__enter__()
             return self
