@@ -169,7 +169,17 @@ def hip_fork(main_stream, side_stream):
     re-used: an event is re-recorded long after its waiter has been enqueued (hipStreamWaitEvent captures the record in flight)."""
     global _hip, _fork_next
     if _hip is None:
-        h = ctypes.CDLL("libamdhip64.so")   # the runtime torch has already loaded
+        # the very runtime torch has loaded (its wheel may bundle its own copy: a second instance would not know torch's streams)
+        path = "libamdhip64.so"
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64.so" in line:
+                        path = line.split()[-1]
+                        break
+        except OSError:
+            pass
+        h = ctypes.CDLL(path)
         h.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
         h.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         h.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]

@@ -414,7 +414,13 @@ class UNet:
             if ev is None and _RAW_EVENTS:
                 # the fork costs the MAIN queue an idle gap per weight-gradient launch (the event's packet sits between two backward-data
                 # kernels): ~6 us with a torch event, less without the system-scope fence a same-device dependency does not need
-                _lib.hip_fork(torch.cuda.current_stream(n.device).cuda_stream, n.wstreams[k].cuda_stream)
+                try:
+                    _lib.hip_fork(torch.cuda.current_stream(n.device).cuda_stream, n.wstreams[k].cuda_stream)
+                except (_lib.RsuError, OSError, AttributeError):   # no usable runtime handle: torch's events do the same, a little slower
+                    globals()["_RAW_EVENTS"] = False
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(n.device))
+                    n.wstreams[k].wait_event(ev)
             else:
                 if ev is None:
                     ev = torch.cuda.Event()
