@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a wedged GPU box must fail a test, not hang the suite: every GPU test gets a generous time limit where pytest-timeout is installed
+    # (the longest one, the 200-pass soak, takes about a minute)
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") is not None and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(1200))
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
