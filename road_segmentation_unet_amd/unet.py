@@ -689,9 +689,17 @@ class UNet:
                 # the last group: nothing is left to run beside it on the main stream (unless the dilated twin of level 0 follows), so
                 # it plans for the whole chip; the level-0 conv1 gradient below is a launch of its own
                 self._flush_wgrads(alone=not (self.dilated and L > 1))
-                with UNet._Side(self, alone=not (self.dilated and L > 1)) as side:
+                if self.wstreams and self._split is not None and not (self.dilated and L > 1) and os.environ.get("RSU_TAIL_MAIN", "1") != "0":
+                    # the pass's last launch needs the backward-data kernel that has just gone out on THIS stream and nothing runs beside
+                    # it: on the main stream it follows back to back -- on the side stream it cost a fork and a join (~24 us of latency in
+                    # the timeline). The side stream's last reduction must be done before the workspace is re-used: joined first.
+                    self._join_side()
                     call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
-                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._ncu, self._stream())
+                         _ptr(self.g["conv_0/conv1/bias"]), _ptr(self.ws_side[0]), B, h, h, nf, 1, self._split[0], st)
+                else:
+                    with UNet._Side(self, alone=not (self.dilated and L > 1)) as side:
+                        call("rsu_conv_first_bwd_weight", _ptr(self.in16), _ptr(dz1), _ptr(self.g["conv_0/conv1/kernel"]), _ptr(self.gfirst[0]),
+                             _ptr(self.g["conv_0/conv1/bias"]), _ptr(side.ws), B, h, h, nf, 1, self._ncu, self._stream())
             if self.dilated and i < L - 1:
                 d1, d2 = a["d1_%d" % i], a["d2_%d" % i]
                 dzd2, dzd1 = g["d2_%d" % i], g["d1_%d" % i]
