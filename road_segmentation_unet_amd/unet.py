@@ -126,6 +126,7 @@ class UNet:
         self._side_active = False   # a weight-gradient launch has gone to the side stream in this backward pass
         self._wg_plans = {}
         self._side_rr = 0
+        self._side_dirty = True
         if training and self.device.type == "cuda" and os.environ.get("RSU_WGRAD_STREAM", "1") == "1":
             nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
             self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
@@ -407,6 +408,7 @@ class UNet:
                 return self
             k = n._side_rr % len(n.wstreams)
             n._side_rr += 1
+            n._side_dirty = True
             self.ws = n.ws_side[k]
             if n._split is not None:
                 n._ncu = n._split[0] if self.alone else n._split[2][k]
@@ -442,8 +444,11 @@ class UNet:
                     n._ncu = n._split[1]
 
     def _join_side(self):
+        if not self._side_dirty:   # nothing has gone to a side stream since the last join: no wait packet on the main queue
+            return
         for s in self.wstreams:
             torch.cuda.current_stream(self.device).wait_stream(s)
+        self._side_dirty = False
 
     def _conv(self, name, srcs, hin, out, dil=1):
         arr = (RsuSrc * len(srcs))(*srcs)
