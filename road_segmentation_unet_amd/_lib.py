@@ -157,40 +157,60 @@ def call(name, *args):
 
 # ---- stream fork without a system-scope fence -------------------------------------------------------------------------------------
 _hip = None
-_fork_events = []
-_fork_next = 0
+_fork_rings = {}   # device index -> [events, next]: HIP events belong to the device that was current when they were created
 
 
-def hip_fork(main_stream, side_stream):
-    """`side_stream` waits for everything issued on `main_stream` so far (both hipStream_t handles as integers), through a HIP event
-    created with hipEventDisableTiming | hipEventDisableSystemFence. torch.cuda.Event releases at system scope (visible to the host and
-    to other devices); a dependency between two streams of ONE device needs agent scope only, and the event's packet holds up the
-    recording queue for less (unet.UNet._Side: one fork per weight-gradient launch, +0.9 % on the step). A ring of 64 events is
-    re-used: an event is re-recorded long after its waiter has been enqueued (hipStreamWaitEvent captures the record in flight)."""
-    global _hip, _fork_next
+def _hip_runtime():
+    """the very runtime torch has loaded (its wheel may bundle its own copy: a second instance would not know torch's streams)"""
+    global _hip
     if _hip is None:
-        # the very runtime torch has loaded (its wheel may bundle its own copy: a second instance would not know torch's streams)
         path = "libamdhip64.so"
         try:
             with open("/proc/self/maps") as f:
                 for line in f:
-                    if "libamdhip64.so" in line:
-                        path = line.split()[-1]
+                    fields = line.split(None, 5)   # address perms offset dev inode pathname (the pathname may end in " (deleted)")
+                    if len(fields) == 6 and "libamdhip64.so" in fields[5]:
+                        cand = fields[5].strip()
+                        if cand.endswith(" (deleted)"):
+                            cand = cand[:-len(" (deleted)")]
+                        if os.path.exists(cand):
+                            path = cand
                         break
         except OSError:
             pass
         h = ctypes.CDLL(path)
         h.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        h.hipEventDestroy.argtypes = [ctypes.c_void_p]
         h.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         h.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
-        for _ in range(64):
-            ev = ctypes.c_void_p()
-            rc = h.hipEventCreateWithFlags(ctypes.byref(ev), 0x2 | 0x20000000)   # hipEventDisableTiming | hipEventDisableSystemFence
-            if rc != 0:
-                raise RsuError("hipEventCreateWithFlags failed (%d)" % rc)
-            _fork_events.append(ev)
         _hip = h
-    ev = _fork_events[_fork_next]
-    _fork_next = (_fork_next + 1) % len(_fork_events)
-    if _hip.hipEventRecord(ev, ctypes.c_void_p(main_stream)) != 0 or _hip.hipStreamWaitEvent(ctypes.c_void_p(side_stream), ev, 0) != 0:
-        raise RsuError("hipEventRecord / hipStreamWaitEvent failed")
+    return _hip
+
+
+def hip_fork(main_stream, side_stream, device_index=None):
+    """`side_stream` waits for everything issued on `main_stream` so far (both hipStream_t handles as integers), through a HIP event
+    created with hipEventDisableTiming | hipEventDisableSystemFence. torch.cuda.Event releases at system scope (visible to the host and
+    to other devices); a dependency between two streams of ONE device needs agent scope only, and the event's packet holds up the
+    recording queue for less (unet.UNet._Side: one fork per weight-gradient launch, +0.9 % on the step). A ring of 64 events PER DEVICE
+    (`device_index`: the device the two streams belong to; None = torch's current device) is re-used: an event is re-recorded long
+    after its waiter has been enqueued (hipStreamWaitEvent captures the record in flight)."""
+    import torch
+    h = _hip_runtime()
+    dev = torch.cuda.current_device() if device_index is None else int(device_index)
+    ring = _fork_rings.get(dev)
+    if ring is None:
+        events = []
+        with torch.cuda.device(dev):
+            for _ in range(64):
+                ev = ctypes.c_void_p()
+                rc = h.hipEventCreateWithFlags(ctypes.byref(ev), 0x2 | 0x20000000)   # hipEventDisableTiming | hipEventDisableSystemFence
+                if rc != 0:
+                    for e in events:   # nothing half-built stays behind
+                        h.hipEventDestroy(e)
+                    raise RsuError("hipEventCreateWithFlags failed (%d) on device %d" % (rc, dev))
+                events.append(ev)
+        ring = _fork_rings[dev] = [events, 0]
+    ev = ring[0][ring[1]]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    if h.hipEventRecord(ev, ctypes.c_void_p(main_stream)) != 0 or h.hipStreamWaitEvent(ctypes.c_void_p(side_stream), ev, 0) != 0:
+        raise RsuError("hipEventRecord / hipStreamWaitEvent failed on device %d" % dev)

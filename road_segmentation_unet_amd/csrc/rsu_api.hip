@@ -666,7 +666,8 @@ extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* 
                                    int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, rsu_stream_t stream) {
     if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !pooled || Cout % 8 || !keep_ok(keep)) return RSU_EINVAL;
     const int Ho = Hin - 2, Wo = Win - 2;
-    if (Ho < 2 || Wo < 2 || ((Ho | Wo) & 1)) return RSU_EINVAL;
+    if (Ho < 2 || Wo < 2) return RSU_EINVAL;
+    const bool even = ((Ho | Wo) & 1) == 0;   // the folded epilogue pools whole 2x2 windows; odd sizes take the two launches (floor semantics, no code bytes)
     // the pool folds into the conv's epilogue where a ping-pong tile shape with whole window rows per wave fits the layer and no dropout
     // follows (its mask is a function of the pooled element index: the separate kernel applies it); otherwise: the two launches
     // ... and where the shapes that can fold it (strip width 16 / 32) cost the conv no extra round of tiles: the pool kernel it saves
@@ -682,7 +683,7 @@ extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* 
         worth = n > 0 && plan_fwd2(a, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, false) &&
                 plan_fwd2(b, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, true) && b.cost <= 1.08 * a.cost;
     }
-    if (keep == 1.f && worth && env_int("RSU_FWD_GEN", 3) >= 3 && env_int("RSU_FWD2_CFG", -1) < 0) {
+    if (keep == 1.f && even && worth && env_int("RSU_FWD_GEN", 3) >= 3 && env_int("RSU_FWD2_CFG", -1) < 0) {
         const int rc = run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, 1, 1, 0, Ho, Wo,
                                1, 1, 1, 0, ncu, (hipStream_t)stream, pooled, code);
         if (rc != RSU_EINVAL) return rc;
@@ -1042,7 +1043,7 @@ extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, floa
     WgGroupTable& T = *(WgGroupTable*)host_table;
     memset(&T, 0, sizeof(T));
     T.magic = WG_TABLE_MAGIC; T.N = N; T.ncu = ncu; T.ws = ws;
-    struct Item { WgPrep w; int family, blocks, nsplit; double cost, unit; };
+    struct Item { WgPrep w; int family, blocks, nsplit, src; double cost, unit; };
     std::array<Item, IGW_GROUP_MAX> it;
     int n = 0;
     double W = 0.0;
@@ -1057,6 +1058,7 @@ extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, floa
             continue;
         }
         a.blocks = a.w.gx * a.w.gy;
+        a.src = i;
         a.cost = wg_family_cost(a.family);
         W += (double)a.blocks * a.w.ntiles * a.cost;
         ++n;
@@ -1070,41 +1072,56 @@ extern "C" int rsu_wgrad_group_plan(const rsu_wgrad_job_t* jobs, int njobs, floa
         double best = 1e300;
         int best_split[IGW_GROUP_MAX] = {0};
         const double ks[5] = {1.0, 1.5, 2.0, 3.0, 4.0};
-        for (int ki = 0; ki < 5; ++ki) {
-            const double target = W / ncu / ks[ki];
-            int split[IGW_GROUP_MAX];
-            std::vector<double> units;
-            double ws_need = 0.0;
-            for (int i = 0; i < n; ++i) {
-                double s = (double)it[i].w.ntiles * it[i].cost / (target > 0 ? target : 1.0);
-                int ns = s < 1.4 ? 1 : (int)(s + 0.5);
-                if (ns > it[i].w.ntiles) ns = it[i].w.ntiles;
-                if (ns < 1) ns = 1;
-                split[i] = ns;
-                const double unit = (double)cdiv(it[i].w.ntiles, ns) * it[i].cost + (ns > 1 ? slab_cost : 0.0);
-                for (int u = 0; u < it[i].blocks * ns; ++u) units.push_back(unit);
-                if (ns > 1) {
-                    ws_need += (double)ns * (double)(it[i].w.main_elems + it[i].w.extra);
+        auto search = [&]() {
+            best = 1e300;
+            for (int ki = 0; ki < 5; ++ki) {
+                const double target = W / ncu / ks[ki];
+                int split[IGW_GROUP_MAX];
+                std::vector<double> units;
+                double ws_need = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    double s = (double)it[i].w.ntiles * it[i].cost / (target > 0 ? target : 1.0);
+                    int ns = s < 1.4 ? 1 : (int)(s + 0.5);
+                    if (ns > it[i].w.ntiles) ns = it[i].w.ntiles;
+                    if (ns < 1) ns = 1;
+                    split[i] = ns;
+                    const double unit = (double)cdiv(it[i].w.ntiles, ns) * it[i].cost + (ns > 1 ? slab_cost : 0.0);
+                    for (int u = 0; u < it[i].blocks * ns; ++u) units.push_back(unit);
+                    if (ns > 1) {
+                        ws_need += (double)ns * (double)(it[i].w.main_elems + it[i].w.extra);
+                    }
+                }
+                if (ws_need > (double)rsu_wgrad_group_ws_floats()) continue;
+                if (units.size() > IGW_UNITS_MAX) continue;
+                std::sort(units.begin(), units.end(), [](double a, double b) { return a > b; });
+                std::vector<double> cu((size_t)ncu, 0.0);   // greedy dispatch: the next unit goes to the CU that falls free first
+                for (double u : units) {
+                    size_t m = 0;
+                    for (size_t c = 1; c < cu.size(); ++c)
+                        if (cu[c] < cu[m]) m = c;
+                    cu[m] += u;
+                }
+                double mk = 0.0;
+                for (double c : cu) mk = c > mk ? c : mk;
+                if (mk < best) {
+                    best = mk;
+                    for (int i = 0; i < n; ++i) best_split[i] = split[i];
                 }
             }
-            if (ws_need > (double)rsu_wgrad_group_ws_floats()) continue;
-            if (units.size() > IGW_UNITS_MAX) continue;
-            std::sort(units.begin(), units.end(), [](double a, double b) { return a > b; });
-            std::vector<double> cu((size_t)ncu, 0.0);   // greedy dispatch: the next unit goes to the CU that falls free first
-            for (double u : units) {
-                size_t m = 0;
-                for (size_t c = 1; c < cu.size(); ++c)
-                    if (cu[c] < cu[m]) m = c;
-                cu[m] += u;
-            }
-            double mk = 0.0;
-            for (double c : cu) mk = c > mk ? c : mk;
-            if (mk < best) {
-                best = mk;
-                for (int i = 0; i < n; ++i) best_split[i] = split[i];
-            }
+            return best < 1e300;
+        };
+        // a group too wide for the unit table or the slab workspace (a deeper or wider net than the benchmarked ones) sheds its largest
+        // job into the per-layer launches behind the group until the rest fits: the plan never fails for size alone
+        while (n > 0 && !search()) {
+            int big = 0;
+            for (int i = 1; i < n; ++i)
+                if ((double)it[i].blocks * it[i].w.ntiles * it[i].cost > (double)it[big].blocks * it[big].w.ntiles * it[big].cost) big = i;
+            W -= (double)it[big].blocks * it[big].w.ntiles * it[big].cost;
+            T.single[T.nsingle++] = jobs[it[big].src];
+            for (int i = big; i + 1 < n; ++i) it[i] = it[i + 1];
+            --n;
         }
-        if (best >= 1e300) return RSU_EINVAL;
+        if (n == 0) return RSU_OK;   // (everything went to per-layer launches: rsu_wgrad_group_run issues them)
         T.plan_makespan = best;
         T.plan_ideal = W / ncu;
         for (int i = 0; i < n; ++i) {

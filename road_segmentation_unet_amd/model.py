@@ -152,9 +152,9 @@ class ConvolutionalModel:
                     self._bucketer.finish()
                 def set_budget(n):   # every candidate budget gets its own (untimed) tile-shape tuning pass before it is timed
                     net.backward_cu_budget = n
-                    net.ensure_tuned()
+                    net.ensure_tuned(keep=float(opts.dropout))
                 self.exchange_schedule = tune_overlap(self._bucketer, probe, trials=2, set_cu_budget=set_budget)
-        net.ensure_tuned()   # the explicit tile-shape tuning pass (untimed, weights untouched): once, in front of the first step
+        net.ensure_tuned(keep=float(opts.dropout))   # the explicit tile-shape tuning pass (untimed, weights untouched): once, in front of the first step
         # feed_dict dropout_keep: opts.dropout (tf_aerial_images.py:237); the masks come from a counter-based hash of
         # (seed, rank, dropout site, global step, element) instead of TF's Philox stream
         net.forward_device(keep=float(opts.dropout))
@@ -399,20 +399,18 @@ class ConvolutionalModel:
 
     # ------------------------------------------------------------------ checkpoints
     def save_as(self, path):
-        """tf_aerial_images.py:458: the saver writing to an explicit path"""
+        """tf_aerial_images.py:458: the saver writing to an explicit path (`path`.npz: every variable under its TF name and layout,
+        its Momentum slot and global_step; '/' in a name is stored as '|' -- np.savez keys become file names)"""
         if self.rank == 0:
             os.makedirs(os.path.dirname(path), exist_ok=True)
             np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in self.net.state_dict().items()})
         return path
 
     def save(self, epoch=0):
-        """tf_aerial_images.py:343-349: {save_path}/{experiment_name}/model-epoch-{epoch:03d}.chkpt(.npz) holding every variable
-        under its TF name and layout, its Momentum slot and global_step."""
+        """tf_aerial_images.py:343-349: {save_path}/{experiment_name}/model-epoch-{epoch:03d}.chkpt(.npz)"""
         opts = self._options
-        path = os.path.abspath(os.path.join(opts.save_path, self.experiment_name, 'model-epoch-{:03d}.chkpt'.format(epoch)))
+        path = self.save_as(os.path.abspath(os.path.join(opts.save_path, self.experiment_name, 'model-epoch-{:03d}.chkpt'.format(epoch))))
         if self.rank == 0:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            np.savez(path + ".npz", **{k.replace("/", "|"): v for k, v in self.net.state_dict().items()})
             print("Model saved in file: {}".format(path))
         return path
 
@@ -443,7 +441,8 @@ class ConvolutionalModel:
 
     def restore(self, date=None, epoch=None, file=None):
         """Restores model from saved checkpoint (tf_aerial_images.py:351-379): explicit file, else newest experiment
-        directory under save_path (or `date`), newest epoch (or `epoch`)."""
+        directory under save_path (or `date`), newest epoch (or `epoch`). As in the reference (tf_aerial_images.py:360), with
+        date=None EVERY directory under save_path takes part in the "newest by name" choice, experiment directory or not."""
         opts = self._options
         if file is not None:
             model_data_dir = file

@@ -118,7 +118,7 @@ class UNet:
         self._split = None     # (full, main, [side ...]) CU budgets while a backward pass shares the chip between the streams
         self.backward_cu_budget = None   # CUs the backward launches may plan for in total (None: the library's default)
         self._ncu = 0          # `ncu` argument of the MFMA launches issued now (0: the library's default budget)
-        self._tuned = set()    # (training?, backward_cu_budget) combinations the tuning pass has run for (tune / ensure_tuned)
+        self._tuned = set()    # (training?, backward_cu_budget, dropout?) combinations the tuning pass has run for (tune / ensure_tuned)
         # grouped weight gradients (rsu.h rsu_wgrad_group_*): the launches of RSU_WG_GROUP consecutive levels / decoder stages of the
         # backward pass go out as ONE launch (0: one launch per layer, as in round 2; "all": one group behind the whole pass)
         self._wg_sizes, self._wg_group = [0], 0   # set per backward pass (_wg_policy)
@@ -417,8 +417,10 @@ class UNet:
                 # the fork costs the MAIN queue an idle gap per weight-gradient launch (the event's packet sits between two backward-data
                 # kernels): ~6 us with a torch event, less without the system-scope fence a same-device dependency does not need
                 try:
-                    _lib.hip_fork(torch.cuda.current_stream(n.device).cuda_stream, n.wstreams[k].cuda_stream)
-                except (_lib.RsuError, OSError, AttributeError):   # no usable runtime handle: torch's events do the same, a little slower
+                    _lib.hip_fork(torch.cuda.current_stream(n.device).cuda_stream, n.wstreams[k].cuda_stream, n.device.index)
+                except (_lib.RsuError, OSError, AttributeError) as ex:   # no usable runtime handle: torch's events do the same, a little slower
+                    import sys
+                    print("road_segmentation_unet_amd: raw HIP fork events unavailable (%r); using torch events" % (ex,), file=sys.stderr)
                     globals()["_RAW_EVENTS"] = False
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(n.device))
@@ -587,6 +589,8 @@ class UNet:
         """Launch the queued weight gradients as grouped launches on the side stream (everything they read has been produced by launches
         issued on the main stream before this point; _Side makes the side stream wait for them). The plan of a group -- which layers,
         which CU share, which workspace -- is made once and kept (host table + its device copy, rsu.h rsu_wgrad_group_plan)."""
+        if not self._wg_pending and not self._wgT_pending:
+            return   # (the data-parallel host asks per bucket boundary: an empty flush must not advance the group schedule)
         self._wg_levels = 0
         self._wg_index += 1
         for pending, tag in ((self._wg_pending, "conv3x3_bwd_weight"), (self._wgT_pending, None)):
@@ -730,15 +734,19 @@ class UNet:
         self._flush_wgrads(alone=True)
         self._join_side()
 
-    def tune(self, training=None):
+    def tune(self, training=None, keep=1.0):
         """The explicit tile-shape tuning pass (rsu.h rsu_set_autotune): ONE untimed forward (+ backward) over random data with the
         library in RSU_TUNE_MEASURE mode -- every conv geometry of this network at the CU shares its launches use is timed once on an
         idle device -- then back to RSU_TUNE_LOOKUP, in which the launch entry points never measure nor synchronise. Weights, Momentum
         slots and the step counter are untouched; x / labels are restored. All shapes give the same bits: this only moves time. Under
-        data parallelism call it before the first collective is in flight (and again after changing backward_cu_budget)."""
+        data parallelism call it before the first collective is in flight (and again after changing backward_cu_budget).
+        `keep` is the dropout keep probability of the steps that follow: with keep < 1 the encoder's conv2 launches take the unfused
+        conv + max-pool pair (rsu.h rsu_conv2d_fwd_pool folds the pool only at keep == 1), whose tuning keys differ from the fused
+        launch's -- the pass must measure the keys the steps will look up."""
         lib = _lib.lib()
         training = self.training if training is None else (training and self.training)
-        self._tuned.add((bool(training), self.backward_cu_budget))
+        keep = float(keep)
+        self._tuned.add((bool(training), self.backward_cu_budget, keep < 1.0))
         if lib.rsu_get_autotune() == _lib.TUNE_OFF or os.environ.get("RSU_AUTOTUNE", "1") == "0":
             return
         x0, l0 = self.x.clone(), self.labels.clone()
@@ -749,7 +757,7 @@ class UNet:
         prof, self.prof = self.prof, None
         call("rsu_set_autotune", _lib.TUNE_MEASURE)
         try:
-            self.forward_device()
+            self.forward_device(keep=keep)
             if training:
                 self.backward_device(1.0 / (self.B * self.P * self.P))
             if self.device.type == "cuda":
@@ -760,11 +768,13 @@ class UNet:
             self.x.copy_(x0)
             self.labels.copy_(l0)
 
-    def ensure_tuned(self, training=None):
-        """tune() once per (forward-only / training, backward CU budget): what the hosts call in front of their first step"""
+    def ensure_tuned(self, training=None, keep=1.0):
+        """tune() once per (forward-only / training, backward CU budget, dropout on / off): what the hosts call in front of their
+        first step"""
         training = self.training if training is None else (training and self.training)
-        if (bool(training), self.backward_cu_budget) not in self._tuned and ((True, self.backward_cu_budget) not in self._tuned):
-            self.tune(training)
+        drop = float(keep) < 1.0
+        if (bool(training), self.backward_cu_budget, drop) not in self._tuned and ((True, self.backward_cu_budget, drop) not in self._tuned):
+            self.tune(training, keep=keep)
 
     # ------------------------------------------------------------------ optimizer
     def learning_rate(self, lr0):
