@@ -14,12 +14,16 @@ Inputs are resident in HBM before the timed region (the reference feeds host num
 discussed in DESIGN.md and is never `value`).
 
 Besides the contract line the JSON carries
-  roofline     : the 3x3-conv MFMA kernels (igemm_fwd = forward + backward-data, igemm_wgrad = backward-weight):
-                 algorithmic FLOPs (2*B*Ho*Wo*Cout*Cin*9 per launch) / HIP-event time of those launches,
-                 measured in an instrumented pass right after the timed region on the launch stream; peak = 2.5 PFLOP/s
-                 dense bf16 MFMA (/opt/skills/guides/MI355X_MICROARCH.md).
-                 The launches are timed in a SERIALISED single-stream pass (each kernel alone on the chip), not in the
-                 two-stream timed region; `traffic` comes from a committed PMC run and is null unless that file was
+  roofline     : the 3x3-conv MFMA kernels (forward, backward-data, backward-weight): algorithmic FLOPs
+                 (2*B*Ho*Wo*Cout*Cin*9 per launch) / the CHIP TIME of those launches in the very schedule `value`
+                 is timed on, measured with HIP events on each launch's own stream in an instrumented pass right behind the
+                 timed region. Chip time of a launch = its duration x the share of the 256 CUs it plans for (its `ncu`
+                 argument): forward launches have the chip to themselves (share 1), in the backward pass a backward-data and a
+                 weight-gradient kernel run side by side on 128 CUs each (share 1/2 each). peak = 2.5 PFLOP/s dense bf16
+                 MFMA (/opt/skills/guides/MI355X_MICROARCH.md). Two serialised single-stream passes (every kernel alone on
+                 the chip) follow for comparison: `frac_serial_per_layer` (one weight-gradient launch per layer, rounds 1-2's
+                 definition) and `frac_single_stream_grouped` (the single-stream product schedule with grouped weight
+                 gradients, round 3's headline). `traffic` comes from a committed PMC run and is null unless that file was
                  measured with this very build of librsu_hip.so (sha-256 match).
   cpu_baseline : the CPU oracle (oracle/unet_oracle.c, kind "port"; TensorFlow 1.4 cannot be installed) timed on the
                  host cores on a bounded sample of the same network, rank 0 / N=1 only.
@@ -27,13 +31,20 @@ Besides the contract line the JSON carries
   sustained    : the same loop run for >= 2 s behind the timed region (clocks and power at steady state).
 
 --workload c4 switches to BASELINE.json configs[3]'s per-GPU share (num_layers=6, 4 patches per GPU) for scaling runs of the
-data-parallel configuration; the default (c2) is the configuration the metric is quoted on.
+data-parallel configuration; --workload c3 to configs[2] (num_layers=6, --dilated_layers, ONE patch per step: the reference's
+final model as it trains it, README.md:49-66); the default (c2) is the configuration the metric is quoted on.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own ranks: it runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...` as a CHILD
+process before anything touches the GPU, relays the ranks' output and exits with the child's return code.
 """
 import hashlib
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -132,6 +143,22 @@ def net_flops(L, root, dilated, P, B):
     return tot, conv3
 
 
+def launch_ranks(nranks, script, script_args, timeout=None):
+    """Start `script` under torch.distributed.run with `nranks` ranks on this node as a child process (never an exec: a process that
+    has touched the GPU must not be replaced), relay its stdout / stderr and return its exit code. One rank per GPU over RCCL
+    (RSU_BENCH_BACKEND=gloo: the ranks share whatever GPUs exist -- tests)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL, CUDA-tensor sharing)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(script_args)
+    proc = subprocess.run(cmd, env=env, timeout=timeout)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,15 +167,19 @@ def main():
     ap.add_argument("--num_layers", type=int, default=5)
     ap.add_argument("--root_size", type=int, default=64)
     ap.add_argument("--patch_size", type=int, default=388)
-    ap.add_argument("--batch_per_gpu", type=int, default=4)
+    ap.add_argument("--batch_per_gpu", type=int, default=None, help="patches per GPU and step (default 4; 1 for --workload c3)")
     ap.add_argument("--dilated_layers", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--workload", default=os.environ.get("RSU_BENCH_WORKLOAD", "c2"), choices=["c2", "c4"],
-                    help="c2: num_layers=5 (headline); c4: num_layers=6, the per-GPU share of the data-parallel configuration")
+    ap.add_argument("--workload", default=os.environ.get("RSU_BENCH_WORKLOAD", "c2"), choices=["c2", "c3", "c4"],
+                    help="c2: num_layers=5 (headline); c3: num_layers=6 dilated, one patch per step (the reference's final model); "
+                         "c4: num_layers=6, the per-GPU share of the data-parallel configuration")
     ap.add_argument("--sustain_seconds", type=float, default=2.0, help="length of the extra steady-state loop (0: skip)")
     ap.add_argument("--cpu_sample_patch", type=int, default=196)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `bench.py --gpus N`: this process becomes the launcher of N ranks (nothing has touched the GPU yet)
+        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,6 +200,12 @@ def main():
 
     if args.workload == "c4":
         args.num_layers = 6
+    if args.workload == "c3":
+        args.num_layers, args.dilated_layers = 6, True
+        if args.batch_per_gpu is None:
+            args.batch_per_gpu = 1   # the reference trains this model at batch 1 (README.md:54)
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 4
     L, root, P, B = args.num_layers, args.root_size, args.patch_size, args.batch_per_gpu
     lib_sha = hashlib.sha256(open(os.path.join(ROOT, "road_segmentation_unet_amd", "librsu_hip.so"), "rb").read()).hexdigest()[:16]
     tune_file = os.environ.get("RSU_AUTOTUNE_FILE")  # profile runs: re-use the tile shapes a previous run measured (no timing launches)
@@ -277,39 +314,61 @@ def main():
                     "payload_MB": m.n_live * 4 / 1e6, "checksum_rank0_local": float(local.item()),
                     "checksum_sum_of_ranks": float(sum_local.item()), "checksum_allreduced_min_over_ranks": float(rmin.item()),
                     "checksum_allreduced_max_over_ranks": float(rmax.item())}
-    # ---- instrumented pass (HIP events on the launch stream around every 3x3-conv MFMA launch)
-    # (single stream here: in the timed region the weight-gradient launches run on a second stream and share the chip with the
-    # backward-data launches, which stretches every launch it overlaps; the roofline figure wants each kernel's own duration)
+    # ---- instrumented passes (HIP events on the launch's own stream around every 3x3-conv MFMA launch)
     nprof = 3
-    m.prof = []
+
+    def instrumented(label):
+        """nprof steps with events around every 3x3-conv launch -> (achieved TFLOP/s over chip time, by_kernel, launches, chip seconds)"""
+        run_step(m, bucketer, lr, mu)   # untimed
+        torch.cuda.synchronize()
+        m.prof = []
+        for _ in range(nprof):
+            run_step(m, bucketer, lr, mu)
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, fl, e0, e1, share in m.prof:
+            a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
+            dur = e0.elapsed_time(e1) * 1e-3
+            a[0] += fl
+            a[1] += dur * share      # chip time: a launch planned for half of the CUs runs beside another one
+            a[2] += 1
+            a[3] += dur
+        m.prof = None
+        fl = sum(a[0] for a in agg.values())
+        t = sum(a[1] for a in agg.values())
+        n = sum(a[2] for a in agg.values())
+        by = {k: {"tflops": v[0] / v[1] / 1e12, "chip_ms_per_step": v[1] / nprof * 1e3, "wall_ms_per_step": v[3] / nprof * 1e3,
+                  "launches": v[2] // nprof} for k, v in agg.items()}
+        return {"achieved": fl / t / 1e12 if t > 0 else 0.0, "by_kernel": by, "launches": n, "chip_s": t, "flops": fl, "label": label}
+
+    # (1) the timed schedule itself: two streams in the backward pass, every launch with the CU share it has there
+    prof_timed = instrumented("timed schedule")
+    # (2), (3) serialised single-stream passes, every launch alone on the chip: one weight-gradient launch per layer (rounds 1-2's
+    # figure), then the single-stream product schedule with grouped weight gradients (round 3's headline figure)
     wstreams, m.wstreams = m.wstreams, []
     if not tune_imported:
         m.tune()                    # on one stream the backward launches plan for the whole chip: shapes not measured yet
-    run_step(m, bucketer, lr, mu)   # untimed
-    torch.cuda.synchronize()
-    m.prof = []
-    for _ in range(nprof):
-        run_step(m, bucketer, lr, mu)
-    torch.cuda.synchronize()
+    wg_env = os.environ.get("RSU_WG_GROUP")
+    os.environ["RSU_WG_GROUP"] = "0"
+    prof_serial = instrumented("single stream, one weight-gradient launch per layer")
+    if wg_env is None:
+        del os.environ["RSU_WG_GROUP"]
+    else:
+        os.environ["RSU_WG_GROUP"] = wg_env
+    prof_grouped = instrumented("single stream, grouped weight gradients") if wstreams else prof_serial
     m.wstreams = wstreams
-    # (the table of measured tile shapes: saved behind BOTH passes -- they plan the backward launches for different CU budgets)
+    # (the table of measured tile shapes: saved behind BOTH schedules -- they plan the backward launches for different CU budgets)
     if tune_file and rank == 0 and not os.path.exists(tune_file):
         cap = lib().rsu_autotune_entries()
         arr = (ctypes.c_int * (17 * max(1, cap)))()
         n = lib().rsu_autotune_export(arr, cap)
         json.dump({"lib_sha16": lib_sha, "rows": list(arr[:17 * n])}, open(tune_file, "w"))
 
-    agg = {}
-    for tag, fl, e0, e1 in m.prof:
-        a = agg.setdefault(tag, [0.0, 0.0, 0])
-        a[0] += fl
-        a[1] += e0.elapsed_time(e1) * 1e-3
-        a[2] += 1
-    m.prof = None
-    conv_fl = sum(a[0] for a in agg.values())
-    conv_t = sum(a[1] for a in agg.values())
-    n_launch = sum(a[2] for a in agg.values())
-    achieved = conv_fl / conv_t / 1e12 if conv_t > 0 else 0.0
+    two_streams = bool(wstreams)
+    achieved = prof_timed["achieved"]
+    n_launch = prof_timed["launches"]
+    conv_t = prof_timed["chip_s"]
+    conv_fl = prof_timed["flops"]
     tot_fl, conv3_fl = net_flops(L, root, args.dilated_layers, P, B)
     # HBM-side bytes per conv launch: PMC counters cannot be read from inside this process; the figure is the one measured with
     # tools/pmc_traffic.sh on this same workload and committed under profiles/rNN/traffic.json (null for any other workload)
@@ -355,17 +414,22 @@ def main():
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                      # the same algorithmic 3x3 FLOPs over the WHOLE timed step (everything else the step does included)
                      "whole_step_frac": conv3_fl * world / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world),
-                     "measured_in": "the product's single-stream schedule run behind the timed region (every launch alone on the chip, HIP "
-                                    "events around each on its launch stream): forward and backward-data launch per layer as in the timed "
-                                    "region; the weight gradients, which the timed two-stream schedule launches per layer on half the chip "
-                                    "beside backward-data, go out here as that schedule's grouped launches (RSU_WG_GROUP, unet.py)",
-                     "kernel": "3x3 conv MFMA kernels: igemm_pp / igemm_fwd2 (forward, backward-data) + igemm_wg_group / igemm_wgpp / igemm_wgrad (weight gradient)",
+                     "measured_in": ("the schedule `value` is timed on, instrumented: HIP events around every 3x3-conv launch on its own stream; "
+                                     + ("forward launches alone on the chip, in the backward pass one backward-data launch (main stream) beside "
+                                        "one weight-gradient launch per layer (side stream), each planned for its share of the CUs; "
+                                        if two_streams else "one stream, every launch alone on the chip; ")
+                                     + "achieved = algorithmic FLOPs / sum over launches of (duration x share of the 256 CUs the launch plans for)"),
+                     "kernel": "3x3 conv MFMA kernels: igemm_pp / igemm_fwd2 (forward, backward-data) + igemm_wgpp / igemm_wgrad / igemm_wg_group (weight gradient)",
                      "launches_per_step": n_launch // nprof,
-                     "avg_launch_us": conv_t / max(1, n_launch) * 1e6,
-                     "conv_ms_per_step": conv_t / nprof * 1e3,
+                     "avg_launch_us": sum(v["wall_ms_per_step"] for v in prof_timed["by_kernel"].values()) / max(1, n_launch // nprof) * 1e3,
+                     "conv_chip_ms_per_step": conv_t / nprof * 1e3,
                      "algorithmic_gflop_per_step": conv_fl / nprof / 1e9,
-                     "by_kernel": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / nprof * 1e3, "launches": v[2] // nprof}
-                                   for k, v in agg.items()}},
+                     "by_kernel": prof_timed["by_kernel"],
+                     # every launch alone on the chip, one stream (no CU shares: chip time == wall time)
+                     "frac_serial_per_layer": prof_serial["achieved"] / MFMA_BF16_PEAK_TFLOPS,
+                     "by_kernel_serial_per_layer": prof_serial["by_kernel"],
+                     "frac_single_stream_grouped": prof_grouped["achieved"] / MFMA_BF16_PEAK_TFLOPS,
+                     "by_kernel_single_stream_grouped": prof_grouped["by_kernel"]},
     }
     if sustained is not None:
         out["sustained"] = sustained

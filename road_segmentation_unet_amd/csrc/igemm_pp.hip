@@ -429,7 +429,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
         const bool inside = co_inside && (T.y0 + TR <= p.Ho) && (T.x0 + SW <= p.Wo);  // wave-uniform
-        if (!p.accumulate) {
+        {
             // forward and backward-data without an AddN: everything on the packed bf16 result. ReLU is a packed int16 max against 0
             // (or, switched off, against the most negative int16: bf16 sign bit == int16 sign bit); the ReLU mask of backward-data
             // (relu_src > 0) is a packed 0 / 0xffff word ANDed onto it: max(x, 0) -> min(., 1) -> 0 - . (a positive NaN in relu_src
@@ -495,54 +495,7 @@ igemm_pp_kernel(const IgFwdParams p) {
             if (p.mask_src) body(true); else body(false);
             return;
         }
-        // every mask / accumulate load of the tile is requested before the first is used: one memory latency per tile, in registers
-        // the stage fragments no longer need (with both a mask and an accumulate source: two batches)
-        constexpr int EB = NST <= 8 ? NST : NST / 2;
-#pragma unroll
-        for (int b0 = 0; b0 < NST; b0 += EB) {
-            unsigned voffs[EB];
-            u32x4 mk4[EB], ob4[EB];
-#pragma unroll
-            for (int e = 0; e < EB; ++e) {
-                voffs[e] = inside ? ovoff[(b0 + e) / (CT / 2)] + ((b0 + e) % (CT / 2)) * 64 : out_voff(T, b0 + e);
-                if (p.mask_src) mk4[e] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, voffs[e], sbase, 0);
-                if (p.accumulate) ob4[e] = __builtin_amdgcn_raw_buffer_load_b128(orsrc, voffs[e], sbase, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < EB; ++e) {
-                const int pt = (b0 + e) / (CT / 2), pp = (b0 + e) % (CT / 2);
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[2 * pp][pt][i];
-                    v[4 + i] = acc[2 * pp + 1][pt][i];
-                }
-                if (p.mask_src) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (!(bf_lo(mk4[e][i]) > 0.f)) v[2 * i] = 0.f;
-                        if (!(bf_hi(mk4[e][i]) > 0.f)) v[2 * i + 1] = 0.f;
-                    }
-                }
-                if (p.accumulate) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[2 * i] += bf_lo(ob4[e][i]);
-                        v[2 * i + 1] += bf_hi(ob4[e][i]);
-                    }
-                }
-                unsigned r0 = pack_bf2(v[0], v[1]), r1 = pack_bf2(v[2], v[3]), r2 = pack_bf2(v[4], v[5]), r3 = pack_bf2(v[6], v[7]);
-                if (p.relu) {
-                    r0 = relu_pk_bf16(r0);
-                    r1 = relu_pk_bf16(r1);
-                    r2 = relu_pk_bf16(r2);
-                    r3 = relu_pk_bf16(r3);
-                }
-                const u32x4 r = {r0, r1, r2, r3};
-                PP_STORE(r, voffs[e]);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the batches apart
-        }
+        // (launches with an AddN -- backward-data into a tensor that already holds a gradient -- stay with igemm_fwd2: igemm_pp_supports)
     };
     auto bar = [&]() {
         asm volatile("" ::: "memory");
@@ -595,13 +548,14 @@ igemm_pp_kernel(const IgFwdParams p) {
         int ck = 0;              // current tile
         Pos cpos = split(tile0);
         Tile ctile = tile_at(cpos);
-        auto chunk = [&](auto parc, int gc) {
-            constexpr int PAR = decltype(parc)::value;
-            seg_begin();
-            if (c == 0 && !(DBG && (p.dbg & 16))) {   // (dbg bit 4: timing without the bias initialisation)
+        // one stage of fragments per wave; they live across a tile boundary in G0 (whose first R interval of the next tile runs BEFORE
+        // the finished tile's epilogue, see below)
+        bf16x8 fa[TPS][CT], fb[TPS][PT];
+        auto bias_init = [&]() {
+            if (!(DBG && (p.dbg & 16))) {   // (dbg bit 4: timing without the bias initialisation)
                 // every accumulator straight from the bias words in LDS: 16 LDS reads instead of 4 reads + 60 register moves (a vector
                 // instruction of an R interval waits for a gap between the partner's MFMAs; an LDS read does not). The reads land before
-                // the s_waitcnt lgkmcnt(0) that ends this R interval.
+                // the s_waitcnt lgkmcnt(0) that ends the interval.
                 const unsigned baddr = (unsigned)(bias_base + (wco * (CT / 2) * 32 + 8 * g4) * 4);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -609,92 +563,159 @@ igemm_pp_kernel(const IgFwdParams p) {
                     for (int pt = 0; pt < PT; ++pt)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(acc[ct][pt]) : "v"(baddr), "n"(((ct >> 1) * 32 + (ct & 1) * 4) * 4) : "memory");
             }
-            seg_end(2);
-            const bool after_epi = (c == 0) && gc > 0;  // the NST stores of the previous tile sit in front of this chunk's issues
-            auto phase = [&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                // ================= R interval: the stage's fragment reads + bookkeeping for the stages ahead
-                bf16x8 fa[TPS][CT], fb[TPS][PT];
-                seg_begin();
-                if (!(DBG && (p.dbg & 32))) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
+        };
+        // ================= R interval of stage J of a chunk whose halo sits in slot PAR: the stage's fragment reads (r_reads) + the
+        // bookkeeping for the stages ahead (r_issue). after_epi: the NST stores of the previous tile sit in front of this interval's
+        // issues (G1 only)
+        auto r_reads = [&](auto parc, auto jc) {
+            constexpr int PAR = decltype(parc)::value, J = decltype(jc)::value;
+            seg_begin();
+            if (!(DBG && (p.dbg & 32))) {  // (dbg bit 5: timing experiment without fragment reads and MFMAs -- the LDS-DMA streams alone)
 #pragma unroll
-                    for (int tl = 0; tl < TPS; ++tl) {
+                for (int tl = 0; tl < TPS; ++tl) {
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct)
-                            fa[tl][ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + afrag + J * WBUF + (tl * WT + ct) * 1024);
-#pragma unroll
-                        for (int pt = 0; pt < PT; ++pt)
-                            fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + boff[pt][tl] + (a_base + PAR * ABUF + J * ROWB));
-                    }
-                }
-                seg_end(3);
-                // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
-                if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
-                    if (!(DBG && (p.dbg & 2))) {
-                        if constexpr (J == 0) a_begin();
-                        a_pieces(gconst, jc);
-                    }
-                }
-                if constexpr (J == 2) a_end();
-                if constexpr ((G ? WP1 : WP0) > 0) {
-                    if (!(DBG && (p.dbg & 1))) issue_w(gconst, (J + 2) % NWB);
-                }
-                seg_end(4);
-                if constexpr (G == 1) {
-                    // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
-                    if (J == 0 && after_epi) {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
-                    } else {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
-                seg_end(5);
-                stamp();
-                bar();
-                stamp();
-                // ================= M interval: the MFMAs of this stage, nothing else
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                if (!(DBG && (p.dbg & 32)))
-#pragma unroll
-                for (int tl = 0; tl < TPS; ++tl)
+                    for (int ct = 0; ct < CT; ++ct)
+                        fa[tl][ct] = *(const __attribute__((address_space(3))) bf16x8*)(lds + afrag + J * WBUF + (tl * WT + ct) * 1024);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[tl][ct], fb[tl][pt]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
-                    if (J == 0 && after_epi) {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
-                    } else if (J == 2) {
-                        RSU_WAIT_VMCNT(WP0);
-                    } else {
-                        RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0);
-                    }
+                        fb[tl][pt] = *(const __attribute__((address_space(3))) bf16x8*)(lds + boff[pt][tl] + (a_base + PAR * ABUF + J * ROWB));
                 }
-                if (J == 2 && c == nchunks - 1) mfma_results_fence();  // straight behind the tile's last MFMA
+            }
+            seg_end(3);
+        };
+        auto r_issue = [&](auto jc, const bool after_epi) {
+            constexpr int J = decltype(jc)::value;
+            // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
+            if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
+                if (!(DBG && (p.dbg & 2))) {
+                    if constexpr (J == 0) a_begin();
+                    a_pieces(gconst, jc);
+                }
+            }
+            if constexpr (J == 2) a_end();
+            if constexpr ((G ? WP1 : WP0) > 0) {
+                if (!(DBG && (p.dbg & 1))) issue_w(gconst, (J + 2) % NWB);
+            }
+            seg_end(4);
+            if constexpr (G == 1) {
+                // G1's share of the next stage (issued one phase ago) must be in LDS behind this interval's barrier
+                if (J == 0 && after_epi) {
+                    RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1 + NST);
+                } else {
+                    RSU_WAIT_VMCNT(pp_na(NAW, 1, J) + WP1);
+                }
+            }
+        };
+        auto r_part = [&](auto parc, auto jc, const bool after_epi) {
+            r_reads(parc, jc);
+            r_issue(jc, after_epi);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments are in registers: the slots they came from may be refilled
+            seg_end(5);
+        };
+        // ================= M interval: the MFMAs of the stage, nothing else
+        auto m_part = [&](auto jc, const bool after_epi, const bool last_of_tile) {
+            constexpr int J = decltype(jc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (!(DBG && (p.dbg & 32)))
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) mfma_bf16_inplace(acc[ct][pt], fa[tl][ct], fb[tl][pt]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (G == 0) {  // G0's share of the next stage (and, in stage 2, of the next halo) must be in LDS behind this interval's barrier
+                // (J == 0 behind a tile boundary: G0 issued R(0)'s pieces BEFORE the finished tile's NST stores -- the same NST + pieces may stay in flight)
+                if (J == 0 && after_epi) {
+                    RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0 + NST);
+                } else if (J == 2) {
+                    RSU_WAIT_VMCNT(WP0);
+                } else {
+                    RSU_WAIT_VMCNT(pp_na(NAW, 0, J) + WP0);
+                }
+            }
+            if (J == 2 && last_of_tile) mfma_results_fence();  // straight behind the tile's last MFMA
+        };
+        auto chunk = [&](auto parc, int gc) {
+            constexpr int PAR = decltype(parc)::value;
+            const bool after_epi = (c == 0) && gc > 0;  // this chunk opens a tile that is not the workgroup's first
+            const bool last_of_tile = c == nchunks - 1;
+            // phase 0. G0 has run R(0) of a tile that is not its first already (in front of the previous tile's epilogue, below)
+            if (!(G == 0 && after_epi)) {
+                seg_begin();
+                if (c == 0) bias_init();
+                seg_end(2);
+                r_part(parc, std::integral_constant<int, 0>{}, after_epi);
                 stamp();
                 bar();
                 stamp();
-            };
-            phase(std::integral_constant<int, 0>{});
-            phase(std::integral_constant<int, 1>{});
-            phase(std::integral_constant<int, 2>{});
-            if (c == nchunks - 1) {
-                // the finished tile's epilogue opens the wave's next R interval (its partner is in an M interval meanwhile)
-                // Tile boundary: both groups store the finished tile in ONE interval of their own, with no MFMAs beside it. A vector
-                // instruction next to the partner's MFMA stream waits ~17 cycles for an issue gap (tools/pp_stamps.py): folded into the
-                // next R interval, each group's epilogue made that interval ~2500 cycles longer than the partner's MFMAs, twice per
-                // tile. Now G0 sits out G1's last MFMA interval, both run their epilogues together at the full issue rate, and G1 sits
-                // out G0's first R interval of the next tile: two short extra intervals instead of two long ones.
-                if constexpr (G == 0) bar();
+            }
+            m_part(std::integral_constant<int, 0>{}, after_epi, last_of_tile);
+            stamp();
+            bar();
+            stamp();
+            r_part(parc, std::integral_constant<int, 1>{}, false);
+            stamp();
+            bar();
+            stamp();
+            m_part(std::integral_constant<int, 1>{}, false, last_of_tile);
+            stamp();
+            bar();
+            stamp();
+            r_part(parc, std::integral_constant<int, 2>{}, false);
+            stamp();
+            bar();
+            stamp();
+            m_part(std::integral_constant<int, 2>{}, false, last_of_tile);
+            stamp();
+            bar();
+            stamp();
+            if (last_of_tile) {
+                // Tile boundary. Both groups store the finished tile in ONE interval of their own, with no MFMAs beside it: a vector
+                // instruction next to the partner's MFMA stream waits ~17 cycles for an issue gap (tools/pp_stamps.py), so an epilogue
+                // folded into an R interval made that interval ~2500 cycles longer than the partner's MFMAs. In global intervals, with S
+                // stages per tile (G0 runs M(S-1) in interval 2S-1, G1 in 2S):
+                //     interval 2S     G1: M(S-1)           G0: the prefetch issues of R(0) of its NEXT tile (what they overwrite was last read
+                //                                              in interval 2S-1)
+                //     interval 2S+1   both: epilogue; G0 then starts its accumulators at the bias and reads the fragments of stage 0 (published
+                //                                              by the barrier closing 2S-1), with no MFMAs beside it
+                //     interval 2S+2   G0: M(0)             G1: R(0)
+                // -- ONE interval without MFMAs per tile. (Rounds 2-3 ran G0's whole R(0) behind the epilogue in an interval of its own, G1
+                // sitting it out: two idle intervals per tile. Reading G0's fragments in interval 2S as well keeps 96 more registers live
+                // across the epilogue: ~100 spilled registers in the four-fragment shapes.)
+                const bool more = ck + 1 < my_tiles;
+                if constexpr (G == 0) {
+                    if (more) r_issue(std::integral_constant<int, 0>{}, false);
+                    stamp();
+                    bar();
+                    stamp();
+                }
                 seg_begin();
                 if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
                 seg_end(0);
+                if constexpr (G == 0) {
+                    if (more) {
+                        bias_init();
+                        if constexpr (PAR == 0) r_reads(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                        else r_reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else {
+                        // (no tile follows: the fragment registers hold no value the loop could still use -- said explicitly, or the compiler
+                        // keeps the previous stage's 96 registers alive across the epilogue for a next iteration that never comes)
+#pragma unroll
+                        for (int tl = 0; tl < TPS; ++tl) {
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) fa[tl][ct] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                            for (int pt = 0; pt < PT; ++pt) fb[tl][pt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        }
+                    }
+                }
+                stamp();
                 bar();
-                if constexpr (G == 1) bar();
+                stamp();
                 c = 0;
                 ++ck;
                 if (ck < my_tiles && !(DBG && (p.dbg & 64))) {   // (dbg bit 6: timing without the tile change)
@@ -713,7 +734,6 @@ igemm_pp_kernel(const IgFwdParams p) {
         }
     };
     if (grp) run_stream(std::integral_constant<int, 1>{}); else run_stream(std::integral_constant<int, 0>{});
-    if (!grp) bar();  // G0 sits out the last interval (G1's last epilogue)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in this workgroup's LDS after it has gone
     if constexpr (STAMP) {
         if (p.stamps) {
@@ -796,7 +816,7 @@ bool igemm_pp_has(int cfg) { return cfg >= 0 && cfg < IGF2_NCFG && cfg != IGF2_C
 // this launch, planned with this geometry, is one the ping-pong kernels are instantiated for (3x3 taps, stride 1, dilation 1, the
 // planner's halo tile for strip width 2^lsw)
 bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
-    if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6) return false;
+    if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6 || p.accumulate) return false;
     const int TM = igemm_fwd2_cfg_info(cfg).TM;
     const int SW = 1 << p.lsw, TR = TM >> p.lsw;
     const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;

@@ -132,7 +132,7 @@ class UNet:
             self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
             self.wstream = self.wstreams[0]
         self.pool_code = {}
-        self.prof = None       # list collecting (tag, algorithmic flops, start event, end event) when profiling
+        self.prof = None       # list collecting (tag, algorithmic flops, start event, end event, CU share) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
         _lib.lib()  # fail loudly now if the HIP extension is missing
         self._check_tensor_sizes()
@@ -337,7 +337,8 @@ class UNet:
         e0.record()
         call(fn, *args)
         e1.record()
-        self.prof.append((tag, flops, e0, e1))
+        # (the share of the chip this launch plans for: bench.py prices a launch's duration by it -- two half-chip launches side by side)
+        self.prof.append((tag, flops, e0, e1, (self._ncu or _lib.lib().rsu_get_cu_budget()) / 256.0))
 
     def _grads_ready(self, name):
         if self.on_grads is not None:  # (dist.GradBucketer waits for the weight-gradient stream itself: extra_streams)

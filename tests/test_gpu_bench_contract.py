@@ -24,6 +24,7 @@ def test_bench_prints_one_contract_line():
     assert d["value"] > 50 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "num_layers=5 root_size=64 patch_size=388" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
+    assert r["measured_in"].startswith("the schedule `value` is timed on") and 0 < r["frac_serial_per_layer"] < 1 and 0 < r["frac_single_stream_grouped"] < 1
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
     assert 0 < r["achieved"] < r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 1e6
@@ -52,3 +53,28 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     ex = d["config"]["dp_exchange"]
     assert ex["backward_cu_budget"] in (256, 240, 224, 208) and len(ex["tuned_ms_per_step"]) == 6 and ex["min_bucket_MB"] in (4, 32)
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None or d["cpu_baseline"]
+
+
+def test_bench_bare_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (how the driver starts the N = 1 run): bench.py launches its two ranks itself as a
+    child torch.distributed.run (gloo here: the test box has one GPU) and relays rank 0's contract line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(RSU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no_cpu_baseline",
+                          "--sustain_seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["dp_exchange"]["exchange_proof"]["world_size"] == 2
+    assert d["roofline"]["measured_in"].startswith("the schedule `value` is timed on")
+
+
+def test_bench_workload_c3_line():
+    """--workload c3: BASELINE configs[2] (num_layers=6, dilated, one patch per step) through the same contract"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--steps", "3", "--warmup", "1", "--no_cpu_baseline",
+                          "--sustain_seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert "num_layers=6" in d["config"]["workload"] and "dilated" in d["config"]["workload"] and d["config"]["batch_per_gpu"] == 1
+    assert d["value"] > 20 and 0 < d["roofline"]["frac"] < 1

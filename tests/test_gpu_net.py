@@ -246,6 +246,44 @@ def test_c2_full_size_step_properties():
         assert e <= 2e-3, (n, e)
 
 
+@pytest.mark.parametrize("wgrad_stream", ["1", "0"])
+def test_c2_benchmarked_batch_of_four_equals_one_patch(wgrad_stream, monkeypatch):
+    """The configuration bench.py times is B = 4: the planner picks tile shapes, strip widths, pixel splits and weight-gradient plans
+    from N * Ho * Wo, so the B = 4 plans are not the ones the oracle comparisons (B = 1) see. Four copies of one patch must give the
+    B = 1 loss (1e-5) and every gradient tensor of the B = 1 step (2e-3 relative Frobenius: fp32 summation order over the batch), in
+    both schedules of the backward pass -- two streams (RSU_WGRAD_STREAM=1, the timed one) and one stream -- after the explicit tuning
+    pass bench.py runs, so that the very tile shapes of the timed region are the ones checked."""
+    monkeypatch.setenv("RSU_WGRAD_STREAM", wgrad_stream)
+    L, root, P = C2
+    S, X1, lab1, params = _setup(L, root, P, 1, False, seed=23)
+    X4, lab4 = np.concatenate([X1] * 4), np.concatenate([lab1] * 4)
+
+    def run(B, X, lab, tune):
+        m = UNet(L, root, False, B, P, params=params, training=True)
+        assert bool(m.wstreams) == (wgrad_stream == "1")
+        if tune:
+            m.tune()
+        m.x.copy_(torch.from_numpy(X))
+        m.labels.copy_(torch.from_numpy(lab))
+        m.forward_device()
+        m.backward_device(1.0 / (B * P * P))
+        torch.cuda.synchronize()
+        return float(m.loss_sum.item()) / (B * P * P), {n: m.g[n].detach().cpu().numpy().copy() for n in m.names}, m.prob.cpu().numpy()
+
+    l4, g4, p4 = run(4, X4, lab4, True)
+    l1, g1, p1 = run(1, X1, lab1, False)
+    assert abs(l4 - l1) <= 1e-5 * abs(l1), (l4, l1)
+    for b in range(4):   # every image of the batch sees the arithmetic of the single patch: the forward pass is bit-identical
+        np.testing.assert_array_equal(p4[b], p1[0])
+    worst = ("", 0.0)
+    for n in g4:
+        assert np.isfinite(g4[n]).all() and np.abs(g4[n]).max() > 0, n
+        e = np.linalg.norm((g4[n] - g1[n]).astype(np.float64)) / np.linalg.norm(g1[n].astype(np.float64))
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e <= 2e-3, (n, e)
+    record("c2_batch4_vs_batch1_wgrad_stream_" + wgrad_stream, loss_b4=l4, loss_b1=l1, worst_grad_rel_err=worst[1], worst_grad_tensor=worst[0])
+
+
 def test_c2_full_size_gradients_match_oracle():
     """config 2 geometry, one patch: loss and EVERY gradient tensor against the bf16-emulating oracle (Frobenius), tolerance =
     max(2e-2, the oracles' own bf16-vs-f32 distance) as in the small cases. ~30 s of oracle time on the host cores: this is the
