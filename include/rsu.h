@@ -170,6 +170,21 @@ int rsu_head_fwd_bwd(const void* act, const float* w, const float* b, const int6
  * All sources share the window size (Hin, Win); y is bf16 [N][Hin-2d][Win-2d][Cout]. */
 int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
                    int Hin, int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream);
+/* The same three launches (rsu_conv2d_fwd, rsu_conv2d_fwd_pool, rsu_conv2d_bwd_data) with a caller-owned workspace `kws` of `kws_floats`
+ * floats (rsu_conv_splitk_ws_floats() is always enough; NULL / 0 = the plain entry points). A layer with far fewer (pixel tile, channel
+ * block) pairs than CUs -- the deep levels of the U-Net at small batches: 18x18 .. 66x66 pixels, 512 .. 2048 channels -- may then cut its
+ * reduction (taps x input channels) into up to 16 slices, one workgroup per (tile, block, slice): the slices' fp32 partial sums go to
+ * `kws` and a second launch sums them IN SLICE ORDER (deterministic), adds nothing else (the bias rides in slice 0), applies ReLU /
+ * the ReLU mask and stores bf16. Results equal the unsplit launch up to the association of the fp32 sum over the slices. Whether a launch
+ * splits is decided by the planner's cost model and, behind a tuning pass, by measurement (RSU_KSPLIT=0: never). The workspace must not
+ * be shared with a launch running concurrently on another stream. */
+size_t rsu_conv_splitk_ws_floats(void);
+int rsu_conv2d_fwd_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
+                     int Hin, int Win, int Cout, int dil, int relu, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
+int rsu_conv2d_fwd_pool_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
+                          int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
+int rsu_conv2d_bwd_data_k(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H, int W,
+                          int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
 /* unet.py:44-52 in one launch: y = relu(conv3x3_valid(concat(srcs), W) + b) (dilation 1), pooled = max_pooling2d(y, 2, 2) followed by
  * the next level's dropout (keep, key as rsu_maxpool2x2_fwd), and -- code != NULL -- the code bytes of rsu_maxpool2x2_fwd_code.
  * The conv's output size must be even. Where a tile shape with whole 2x2 windows per wavefront fits the layer and keep == 1 the

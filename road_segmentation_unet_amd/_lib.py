@@ -73,6 +73,10 @@ SIGNATURES = {
     "rsu_conv2d_fwd": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv2d_fwd_pool": (_i, [_PS, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u, _i, _vp]),
     "rsu_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv_splitk_ws_floats": (_sz, []),
+    "rsu_conv2d_fwd_k": (_i, [_PS, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "rsu_conv2d_fwd_pool_k": (_i, [_PS, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u, _i, _vp, _sz, _vp]),
+    "rsu_conv2d_bwd_data_k": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_wgrad_group_table_bytes": (_sz, []),

@@ -38,6 +38,15 @@ struct IgFwdParams {
     int relu, accumulate;
     int ncob;
     int lsw;              // log2(g.SW) for the aligned-tile kernels (igemm_fwd2)
+    // igemm_pp only. ksplit > 1: the reduction (the 32-channel chunks of all sources) is cut into ksplit contiguous slices, one workgroup
+    // per (pixel tile, channel block, slice); a workgroup writes its fp32 partial sums to kslab (slice z at kslab + z * kslab_stride
+    // floats, tile slot (tile * ncob + cob) * 2 * NST * 8 KiB inside it, in register order) and igemm_pp_finish_launch sums the slices in
+    // order, applies bias (inside slice 0), ReLU / ReLU mask and stores bf16. cob_group (a divisor of ncob * ksplit, 0 = all): how many
+    // (channel block, slice) units of one pixel tile sit on neighbouring workgroup ids (= on one XCD); the rest of an XCD's run walks the pixel
+    // tiles -- weight-heavy layers want few units per XCD (each weight slice through ONE L2), halo-heavy layers all of them
+    int ksplit, cob_group;
+    float* kslab;
+    long kslab_stride;
     int dbg;              // developer A/B switch (RSU_FWD_DBG): bit 0 = skip weight staging, bit 1 = skip halo staging (timing only)
     unsigned* stamps;     // diagnostic time stamps of igemm_pp (RSU_FWD_DBG bit 7 + RSU_STAMP_PTR), else null
     TileGeo g;
@@ -53,9 +62,14 @@ size_t igemm_fwd2_lds_bytes(int cfg, int ntap, int npix_max);
 hipError_t igemm_fwd2_launch(int cfg, int ntap, const IgFwdParams& p, int grid_x, int grid_y, hipStream_t st);
 // third generation (ping-pong wave groups; igemm_pp.hip): 3x3 taps, stride 1; tile shapes, LDS budget and results as igemm_fwd2
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);
+hipError_t igemm_pp_d2_launch(int cfg, const IgFwdParams& p, int grid_x, hipStream_t st);   // the same for dilation 2 (igemm_pp_d2.hip)
+bool igemm_pp_d2_supports(int cfg, const IgFwdParams& p);
 bool igemm_pp_has(int cfg);  // tile shapes the ping-pong kernel is built for
+bool igemm_pp_has_ksplit(int cfg);   // ... and its split-K instantiations
 bool igemm_pp_supports(int cfg, const IgFwdParams& p);  // ... and this planned launch is one of its instantiations
 int igemm_pp_pool_lsw_mask(int cfg);  // strip widths (bit lsw) at which the shape can fold the 2x2 max-pool into its epilogue (0: none)
+size_t igemm_pp_slab_floats(int cfg, const IgFwdParams& p);   // floats of ONE slice of the split-K slab of this planned launch
+hipError_t igemm_pp_finish_launch(int cfg, const IgFwdParams& p, hipStream_t st);   // sums the slices of a split-K launch into p.out
 
 // ---------------------------------------------------------------------------------------------
 // igemm_ct (igemm_ct.hip): the 2x2 stride-2 transposed convolution as a ping-pong GEMM over the low-resolution pixels m = (n, y, x)

@@ -26,9 +26,16 @@
 //   * halo: ring of 2 chunk slots; the slot of chunk c-1 is free from interval 6c on. The pieces of chunk c+1 are issued in G0's
 //     R(3c), R(3c+1), R(3c+2) and G1's R(3c), R(3c+1) (always in front of the interval's weight pieces) and are covered by the
 //     same counted waits in interval 6c+5.
+#include <cstring>
 #include <type_traits>
 
 #include "igemm.h"
+
+// PP_DIL: the dilation this translation unit is built for (1: igemm_pp.hip itself; 2: igemm_pp_d2.hip, which includes this file with the
+// exported names changed -- the dilated twin blocks of unet.py:32-39). The halo tile is 2 * DIL wider and higher, taps are DIL pixels apart.
+#ifndef PP_DIL
+#define PP_DIL 1
+#endif
 
 #define RSU_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define RSU_SENT 0x80000000u   // voffset that the range check always rejects (num_records = 0x7fffffff)
@@ -68,7 +75,8 @@ constexpr int pp_na_idx(int NAW, int g, int j) {  // index of the slot's first p
     return n;
 }
 }  // namespace
-template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG, bool POOLK = false>
+// KS: the split-K instantiations (IgFwdParams::ksplit > 1; the others ignore it -- their reduction bookkeeping stays compile-time lean)
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAW, int WP0, bool STAMP, bool DBG, bool POOLK = false, bool KS = false, int DIL = PP_DIL>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 igemm_pp_kernel(const IgFwdParams p) {
     constexpr int NW = 8, NG = 4, KW = 3, TPS = 3;
@@ -90,10 +98,10 @@ igemm_pp_kernel(const IgFwdParams p) {
     // become immediate offsets of the LDS reads and most of the scalar arithmetic of an R interval disappears (an R-interval
     // instruction costs ~6 cycles of a budget of ~290: probes/probe_mfma_rate.hip)
     constexpr int SW = 1 << LSW, lsw = LSW, TR = TM >> LSW;
-    constexpr int CW = (SW + 2 + 7) / 8 * 8;              // halo row pitch in pixels (plan_geo_aligned)
-    constexpr int NPIX = ((TR + 2) * CW + 31) / 32 * 32;  // halo pixels per slot
+    constexpr int CW = (SW + 2 * DIL + 7) / 8 * 8;              // halo row pitch in pixels (plan_geo_aligned)
+    constexpr int NPIX = ((TR + 2 * DIL) * CW + 31) / 32 * 32;  // halo pixels per slot
     constexpr int ABUF = NPIX * 64;
-    constexpr int ROWB = CW * 64;                         // one kernel row down in the halo tile
+    constexpr int ROWB = DIL * CW * 64;                         // one kernel row (DIL image rows) down in the halo tile
     constexpr int a_base = 0;                             // LDS: [halo slot 0][halo slot 1][weight slots 0..2][scratch][bias]
     constexpr int WBASE = NAB * ABUF;
     constexpr int dummy_base = WBASE + NWB * WBUF;        // 1 KiB scratch slot for padding loads
@@ -105,27 +113,52 @@ igemm_pp_kernel(const IgFwdParams p) {
     const int wco = wave / WPX, wpx = wave % WPX;
     const int g4 = lane >> 4, l15 = lane & 15;
 
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     // ---- this workgroup's tile list (XCD-aware numbering as in igemm_fwd2)
     int vid = blockIdx.x;
     {
         const int q = gridDim.x >> 3, r = gridDim.x & 7, x = vid & 7;
         vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
     }
-    const int cob = vid % p.ncob;
-    const int tile0 = vid / p.ncob, tstride = gridDim.x / p.ncob;
+    // (channel block, reduction slice) units per pixel tile; `cgrp` of them on neighbouring ids, then the pixel tiles of the workgroup
+    // column, then the next group of units: cgrp = nck is the numbering of rounds 1-3 (all units of a tile together: they share its halo),
+    // cgrp = 1 keeps a weight slice inside one XCD's run
+    const int ksplit = (KS && p.ksplit > 1) ? p.ksplit : 1;
+    const int nck = p.ncob * ksplit;
+    const int cgrp = (p.cob_group > 0 && p.cob_group < nck) ? p.cob_group : nck;
+    const int tstride = sgpr(gridDim.x / nck);
+    const int u_in = vid % cgrp, u_r = vid / cgrp;
+    const int unit = sgpr((u_r / tstride) * cgrp + u_in);
+    const int tile0 = sgpr(u_r % tstride);
+    const int cob = sgpr(unit % p.ncob), ks = KS ? sgpr(unit / p.ncob) : 0;
     const int tpi = p.g.nstrips * p.g.tiles_per_strip;
     const int ntile_m = p.N * tpi;
-    const int my_tiles = tile0 < ntile_m ? (ntile_m - tile0 + tstride - 1) / tstride : 0;
+    const int my_tiles = (unit < nck && tile0 < ntile_m) ? (ntile_m - tile0 + tstride - 1) / tstride : 0;
     if (my_tiles == 0) return;
     const int nchunks = p.nchunk[0] + p.nchunk[1] + p.nchunk[2];
-    const int GC = my_tiles * nchunks;  // chunks in this workgroup's stream
+    // this workgroup's slice of the reduction: chunks [c_lo, c_hi) of every one of its tiles (all of them without split-K)
+    const int c_lo = KS ? sgpr(ks * nchunks / ksplit) : 0, c_hi = KS ? sgpr((ks + 1) * nchunks / ksplit) : nchunks;
+    const int nloc = c_hi - c_lo;
+    // the concat source that holds chunk c_lo, the chunk's index inside it, and the chunk index at which the next source begins
+    int src_lo = 0, coff_lo = c_lo, next_lo = p.nchunk[0];
+    if (KS && coff_lo >= p.nchunk[0] && p.nsrc > 1) {
+        coff_lo -= p.nchunk[0];
+        src_lo = 1;
+        next_lo += p.nchunk[1];
+        if (coff_lo >= p.nchunk[1] && p.nsrc > 2) {
+            coff_lo -= p.nchunk[1];
+            src_lo = 2;
+            next_lo += p.nchunk[2];
+        }
+    }
+    const int next_rel = next_lo - c_lo;   // ... counted from c_lo, as the prefetch stream counts
+    const int GC = my_tiles * nloc;  // chunks in this workgroup's stream
 
     // this workgroup's tiles are tile0, tile0 + tstride, ...: (image, strip, row in strip) of the first one by division, then stepped --
     // a run-time division costs ~20 vector instructions, and a vector instruction of an R interval waits for a gap between the
     // partner wave's MFMAs (~17 cycles each, tools/pp_stamps.py)
     struct Tile { int n, x0, y0; };
     struct Pos { int n, strip, row; };
-    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto split = [&](int t) {
         const int n = t / tpi, r = t - n * tpi;
         const int strip = r / p.g.tiles_per_strip;
@@ -150,7 +183,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int hp0 = ty * CW + tx;
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
-            const int hp = hp0 + kx;
+            const int hp = hp0 + kx * DIL;
             boff[pt][kx] = (hp << 6) + ((g4 ^ ((hp >> 1) & 2)) << 4);  // CW % 8 == 0: a ky shift keeps the swizzle
         }
     }
@@ -163,9 +196,9 @@ igemm_pp_kernel(const IgFwdParams p) {
     // weights; a wave's WPS pieces have constant offsets inside it (folded into the per-lane voffset), the stage is one scalar
     // offset that advances by a constant and rewinds per tile. The stream never ends: behind the last stage it simply starts the
     // tile's weights again (valid memory, slots nobody reads), so the counted waits hold to the very end.
-    const int nstage_tile = nchunks * 3;
+    const int nstage_tile = nloc * 3;
     const unsigned stage_bytes = (unsigned)TPS * p.ntiles_w * 1024;
-    const unsigned w_tile_soff = (unsigned)(p.tile_off + cob * WT) * 1024u;
+    const unsigned w_tile_soff = (unsigned)(p.tile_off + cob * WT) * 1024u + (unsigned)(c_lo * 3) * stage_bytes;
     unsigned w_soff = w_tile_soff;     // stage to prefetch next
     int w_sit = 0;                     // its stage index inside the tile
     unsigned w_voff[WPM];              // per-lane byte offset of this wave's piece q inside a stage block
@@ -194,9 +227,9 @@ igemm_pp_kernel(const IgFwdParams p) {
     const char* a_ptr = nullptr;   // current source, shifted back by the padding so that every in-window offset is >= 0
     unsigned a_soff = 0;           // byte offset of the (padded) halo origin + channel chunk in that source
     int a_crem = 0;                // channels left in the current source (>= 32 except in a partial last chunk)
-    int a_cl = 0;                  // chunk (inside its tile) of the next halo to prefetch
+    int a_cl = 0;                  // chunk (inside this workgroup's slice of its tile: 0 = chunk c_lo) of the next halo to prefetch
     int a_next_src = 0;            // chunk index at which the next source begins
-    int a_si = 0;                  // current source
+    int a_si = src_lo;             // current source
     int ia_slot = 0;               // ring slot of the next halo
     auto my_piece = [&](int idx) {  // halo piece (per chunk) behind entry idx of this wave's offset array
         int pw = 0;
@@ -209,7 +242,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         }
         return pw * NG + w4;
     };
-    auto setup_a = [&](const Tile& T, int si) {
+    auto setup_a = [&](const Tile& T, int si, int coff) {   // source si from its chunk coff on
         const bf16_t* sptr = si == 0 ? p.src[0].ptr : (si == 1 ? p.src[1].ptr : p.src[2].ptr);
         const int sH = si == 0 ? p.src[0].H : (si == 1 ? p.src[1].H : p.src[2].H);
         const int sW = si == 0 ? p.src[0].W : (si == 1 ? p.src[1].W : p.src[2].W);
@@ -217,8 +250,8 @@ igemm_pp_kernel(const IgFwdParams p) {
         const int soy = si == 0 ? p.src[0].oy : (si == 1 ? p.src[1].oy : p.src[2].oy);
         const int sox = si == 0 ? p.src[0].ox : (si == 1 ? p.src[1].ox : p.src[2].ox);
         a_ptr = (const char*)(sptr - ((long)p.pad * sW + p.pad) * sC);
-        a_soff = (unsigned)((((long)(T.n * sH + T.y0 + soy) * sW + (T.x0 + sox)) * sC) * 2);
-        a_crem = sC;
+        a_soff = (unsigned)((((long)(T.n * sH + T.y0 + soy) * sW + (T.x0 + sox)) * sC) * 2) + (unsigned)coff * 64u;
+        a_crem = sC - coff * 32;
         const int iy0 = T.y0 - p.pad, ix0 = T.x0 - p.pad;
 #pragma unroll
         for (int q = 0; q < NAV; ++q) {
@@ -244,15 +277,15 @@ igemm_pp_kernel(const IgFwdParams p) {
                 }
                 if (!(DBG && (p.dbg & 256))) {   // (dbg bit 8: timing without the prefetch stream's tile change)
                     ptile = tile_at(ppos);
-                    setup_a(ptile, 0);
+                    setup_a(ptile, src_lo, coff_lo);
                 }
-                a_si = 0;
-                a_next_src = p.nchunk[0];
+                a_si = src_lo;
+                a_next_src = next_rel;
             }
         } else if (a_cl == a_next_src) {
             ++a_si;
             a_next_src += a_si == 1 ? p.nchunk[1] : p.nchunk[2];
-            setup_a(ptile, a_si);
+            setup_a(ptile, a_si, 0);
         }
         a_started = true;
     };
@@ -283,7 +316,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         ia_slot ^= 1;
         a_soff += 64;
         a_crem -= 32;
-        a_cl = a_cl + 1 == nchunks ? 0 : a_cl + 1;
+        a_cl = a_cl + 1 == nloc ? 0 : a_cl + 1;
     };
 
     // bias of this workgroup's TN channels lives in LDS (behind the scratch slot)
@@ -313,7 +346,7 @@ igemm_pp_kernel(const IgFwdParams p) {
     };
     if (threadIdx.x < TN) {
         const int co = cob * TN + threadIdx.x;
-        const float bvv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        const float bvv = (p.bias && co < p.Cout && ks == 0) ? p.bias[co] : 0.f;   // (split-K: the bias rides in slice 0's partial sums)
         *(__attribute__((address_space(3))) float*)(lds + bias_base + threadIdx.x * 4) = bvv;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ordinary loads before the LDS-DMA stream starts
@@ -424,7 +457,22 @@ igemm_pp_kernel(const IgFwdParams p) {
             }
         }
     };
-    auto epilogue = [&](const Tile& T, f32x4(&acc)[CT][PT]) {
+    auto epilogue = [&](const Tile& T, const int tidx, f32x4(&acc)[CT][PT]) {
+        if constexpr (KS) {   // split-K: the slice's fp32 partial sums in register order, 1 KiB per store; k_pp_splitk_finish sums them
+            const unsigned long long kaddr = (unsigned long long)(p.kslab + (long)ks * p.kslab_stride);
+            const __amdgpu_buffer_rsrc_t krsrc = mk((const void*)(((unsigned long long)(unsigned)sgpr((int)(kaddr >> 32)) << 32) | (unsigned)sgpr((int)kaddr)));
+            const unsigned kbase = (unsigned)sgpr((((tidx * p.ncob + cob) * NW + wave) * NST) * 2048);
+            const unsigned kvoff = (unsigned)lane * 16u;
+#pragma unroll
+            for (int e = 0; e < NST; ++e) {
+                const int pt = e / (CT / 2), pp = e % (CT / 2);
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(acc[2 * pp][pt]), "v"(kvoff), "s"(krsrc),
+                             "s"(kbase + (unsigned)(e * 2048)) : "memory");
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(acc[2 * pp + 1][pt]), "v"(kvoff), "s"(krsrc),
+                             "s"(kbase + (unsigned)(e * 2048 + 1024)) : "memory");
+            }
+            return;
+        }
         const __amdgpu_buffer_rsrc_t orsrc = mk(p.out);
         const __amdgpu_buffer_rsrc_t mrsrc = mk(p.mask_src ? (const void*)p.mask_src : (const void*)p.out);
         const unsigned sbase = out_sbase(T);
@@ -506,8 +554,8 @@ igemm_pp_kernel(const IgFwdParams p) {
     // ---- prologue: every wave issues its share of the halo of chunk 0 and of the weights of stages 0 and 1 and waits for all of
     // it; one barrier publishes the lot (raw barrier: __syncthreads() would drain the LDS-DMA stream on every later use; the bias
     // words above are the only ordinary LDS stores)
-    setup_a(ptile, 0);
-    a_next_src = p.nchunk[0];
+    setup_a(ptile, src_lo, coff_lo);
+    a_next_src = next_rel;
     a_begin();
     if (!(DBG && (p.dbg & 2))) {
         if (grp) {
@@ -641,7 +689,7 @@ igemm_pp_kernel(const IgFwdParams p) {
         auto chunk = [&](auto parc, int gc) {
             constexpr int PAR = decltype(parc)::value;
             const bool after_epi = (c == 0) && gc > 0;  // this chunk opens a tile that is not the workgroup's first
-            const bool last_of_tile = c == nchunks - 1;
+            const bool last_of_tile = c == nloc - 1;
             // phase 0. G0 has run R(0) of a tile that is not its first already (in front of the previous tile's epilogue, below)
             if (!(G == 0 && after_epi)) {
                 seg_begin();
@@ -693,7 +741,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                     stamp();
                 }
                 seg_begin();
-                if (!(DBG && (p.dbg & 8))) epilogue(ctile, acc);
+                if (!(DBG && (p.dbg & 8))) epilogue(ctile, KS ? (cpos.n * p.g.nstrips + cpos.strip) * p.g.tiles_per_strip + cpos.row : 0, acc);
                 seg_end(0);
                 if constexpr (G == 0) {
                     if (more) {
@@ -748,6 +796,67 @@ igemm_pp_kernel(const IgFwdParams p) {
     }
 }
 
+#if PP_DIL == 1
+// ---------------------------------------------------------------------------------------------
+// split-K finish: out[pixel][8 channels] = bf16(epilogue(sum over the slices, in slice order, of the partial sums)) -- one thread per
+// (tile slot, wave, store e, lane) of the conv kernel's epilogue, i.e. per 16-byte output store: it reads its two float4 of every slice
+// (1 KiB per wavefront and slice, contiguous), sums them in a fixed order (deterministic), applies ReLU (or not) and the ReLU mask of
+// backward-data exactly as the conv epilogue does (packed bf16), and stores where that epilogue would have stored.
+struct PpFinishParams {
+    const float* slab;
+    long slice_stride;     // floats
+    int ksplit, nslots, ncob;
+    int WCO, WPX, CT, PT, lsw, TR;
+    int nstrips, tiles_per_strip;
+    bf16_t* out;
+    const bf16_t* mask_src;
+    int Ho, Wo, oH, oW, outC, Cout, relu;
+};
+__global__ void __launch_bounds__(256) k_pp_splitk_finish(const PpFinishParams q) {
+    const int NST = (q.CT / 2) * q.PT, TN = q.WCO * q.CT * 16;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(idx & 63);
+    long r = idx >> 6;
+    const int e = (int)(r % NST); r /= NST;
+    const int wave = (int)(r & 7); r >>= 3;
+    const int slot = (int)r;
+    if (slot >= q.nslots) return;
+    const float* src = q.slab + ((long)(slot * 8 + wave) * NST + e) * 512 + lane * 4;   // 2 KiB = 512 floats per (wave, e): two 1-KiB halves
+    f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 256);
+    for (int z = 1; z < q.ksplit; ++z) {
+        const float* sz = src + (long)z * q.slice_stride;
+        a += *(const f32x4*)sz;
+        b += *(const f32x4*)(sz + 256);
+    }
+    const int cob = slot % q.ncob, t = slot / q.ncob;
+    const int tpi = q.nstrips * q.tiles_per_strip;
+    const int n = t / tpi, tr = t - n * tpi;
+    const int strip = tr / q.tiles_per_strip, row = tr - strip * q.tiles_per_strip;
+    const int wco = wave / q.WPX, wpx = wave % q.WPX;
+    const int pt = e / (q.CT / 2), pp = e % (q.CT / 2);
+    const int g4 = lane >> 4, l15 = lane & 15;
+    const int ml = (wpx * q.PT + pt) * 16 + l15;
+    const int SW = 1 << q.lsw;
+    const int y = row * q.TR + (ml >> q.lsw), x = strip * SW + (ml & (SW - 1));
+    const int co = cob * TN + (wco * (q.CT / 2) + pp) * 32 + 8 * g4;
+    if (y >= q.Ho || x >= q.Wo || co >= q.Cout) return;
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    const short fl = q.relu ? (short)0 : (short)-32768;
+    const s2 floor2 = {fl, fl};
+    auto pk = [&](float lo, float hi) {   // two results -> packed bf16, ReLU (or not) as the conv epilogue applies it: a packed int16 max
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, pack_bf2(lo, hi)), floor2));
+    };
+    u32x4 v = {pk(a[0], a[1]), pk(a[2], a[3]), pk(b[0], b[1]), pk(b[2], b[3])};
+    const long off = (((long)n * q.oH + y) * q.oW + x) * q.outC + co;
+    if (q.mask_src) {
+        const u32x4 m = *(const u32x4*)(q.mask_src + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] &= pos_mask_pk_bf16(m[i]);
+    }
+    *(u32x4*)(q.out + off) = v;
+}
+
+#endif   // PP_DIL == 1
 // ---------------------------------------------------------------------------------------------
 template <int CFG> struct PpCfg;
 #define PP_NAS(a, b, c, d, e) ((a) | ((b) << 4) | ((c) << 8) | ((d) << 12) | ((e) << 16))
@@ -760,9 +869,9 @@ template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX =
 template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NAS = PP_NAS(0, 3, 3, 2, 2), WP0 = 0; };
 // (128x320 / 64x640, five pixel fragments per wave: measured 20-40 % slower than igemm_fwd2's -- three taps of fragments beside 80
 // accumulators leave no registers for the tile bookkeeping; not instantiated)
-template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG, bool POOLK = false>
+template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG, bool POOLK = false, bool KS = false>
 static hipError_t pp_launch_kernel3(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
-    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG, POOLK>;
+    auto kern = igemm_pp_kernel<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG, POOLK, KS, PP_DIL>;
     const size_t lds = igemm_fwd2_lds_bytes(cfg, 9, p.g.npix_max) + (STAMP ? 8 * PP_NSTAMP * 4 : 0);  // same rings as igemm_fwd2's 9-tap kernels
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -775,28 +884,35 @@ static hipError_t pp_launch_kernel3(int cfg, const IgFwdParams& p, int gx, hipSt
 }
 template <int WCO, int WPX, int CT, int PT, int LSW, int NAS, int WP0, bool STAMP, bool DBG>
 static hipError_t pp_launch_kernel2(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
-    if constexpr (!STAMP && !DBG && ((PT == 4 && (LSW == 4 || LSW == 5)) || (PT == 2 && LSW == 4))) {
+    if constexpr (PP_DIL == 1 && !STAMP && !DBG && ((PT == 4 && (LSW == 4 || LSW == 5)) || (PT == 2 && LSW == 4))) {
         if (p.pool_out) return pp_launch_kernel3<WCO, WPX, CT, PT, LSW, NAS, WP0, false, false, true>(cfg, p, gx, st);
     }
     if (p.pool_out) return hipErrorInvalidValue;   // (the planner only asks for the pool where igemm_pp_pool_lsw_mask allows it)
+    if (p.ksplit > 1) {   // split-K: instantiated for the 128-channel shapes (the deep layers, which are the ones short of pixel tiles)
+        if constexpr (!STAMP && !DBG && WCO == 2) {
+            if (!p.kslab) return hipErrorInvalidValue;
+            return pp_launch_kernel3<WCO, WPX, CT, PT, LSW, NAS, WP0, false, false, false, true>(cfg, p, gx, st);
+        }
+        return hipErrorInvalidValue;
+    }
     return pp_launch_kernel3<WCO, WPX, CT, PT, LSW, NAS, WP0, STAMP, DBG, false>(cfg, p, gx, st);
 }
 // strip widths an instantiation exists for: the halo tile must fit the DMA pieces of a chunk and the 16-bit offsets of the LDS reads
 constexpr bool pp_geo_ok(int TM, int LSW, int NAS) {
     const int SW = 1 << LSW, TR = TM >> LSW;
     if (TR < 1 || TR * SW != TM) return false;
-    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    const int CW = (SW + 2 * PP_DIL + 7) / 8 * 8, NPIX = ((TR + 2 * PP_DIL) * CW + 31) / 32 * 32;
     int pieces = 0;
     for (int k = 0; k < 5; ++k) pieces += pp_na_slot(NAS, k);
-    return NPIX <= pieces * 4 * 16 && NPIX * 64 + 2 * CW * 64 < 65536;
+    return NPIX <= pieces * 4 * 16 && NPIX * 64 + 2 * PP_DIL * CW * 64 < 65536;
 }
 // the kernel is instantiated per strip width (2^LSW = 8 .. 64): the planner's geometry must be the one the instantiation assumes
 template <int WCO, int WPX, int CT, int PT, int NAS, int WP0, bool STAMP, bool DBG = false>
 static hipError_t pp_launch_kernel(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     constexpr int TM = WPX * PT * 16;
     const int SW = 1 << p.lsw, TR = TM >> p.lsw;
-    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
-    if (p.dil != 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX || TR < 1) return hipErrorInvalidValue;
+    const int CW = (SW + 2 * PP_DIL + 7) / 8 * 8, NPIX = ((TR + 2 * PP_DIL) * CW + 31) / 32 * 32;
+    if (p.dil != PP_DIL || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX || TR < 1) return hipErrorInvalidValue;
     switch (p.lsw) {
         case 3: if constexpr (pp_geo_ok(TM, 3, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 3, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
         case 4: if constexpr (pp_geo_ok(TM, 4, NAS)) return pp_launch_kernel2<WCO, WPX, CT, PT, 4, NAS, WP0, STAMP, DBG>(cfg, p, gx, st); break;
@@ -812,14 +928,21 @@ static hipError_t pp_launch_one(const IgFwdParams& p, int gx, hipStream_t st) {
 }
 // (the five-fragment shapes are instantiated but lose: three taps of fragments beside 80 accumulators leave no room for the tile
 // bookkeeping, whose spills cost more than the lean loop gains; igemm_fwd2 keeps them)
+#if PP_DIL == 1
 bool igemm_pp_has(int cfg) { return cfg >= 0 && cfg < IGF2_NCFG && cfg != IGF2_CFG_128x320 && cfg != IGF2_CFG_64x640; }
+#endif
 // this launch, planned with this geometry, is one the ping-pong kernels are instantiated for (3x3 taps, stride 1, dilation 1, the
 // planner's halo tile for strip width 2^lsw)
+#if PP_DIL == 1
+bool igemm_pp_has_ksplit(int cfg) { return cfg == IGF2_CFG_128x256 || cfg == IGF2_CFG_128x128 || cfg == IGF2_CFG_128x192; }
+#endif
 bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
-    if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != 1 || p.lsw < 3 || p.lsw > 6 || p.accumulate) return false;
+    if (!igemm_pp_has(cfg) || p.stride != 1 || p.ostride != 1 || p.dil != PP_DIL || p.lsw < 3 || p.lsw > 6 || p.accumulate) return false;
+    if (p.ksplit > 1 && (!igemm_pp_has_ksplit(cfg) || p.pool_out || !p.kslab)) return false;
+    if (p.pool_out && PP_DIL != 1) return false;
     const int TM = igemm_fwd2_cfg_info(cfg).TM;
     const int SW = 1 << p.lsw, TR = TM >> p.lsw;
-    const int CW = (SW + 2 + 7) / 8 * 8, NPIX = ((TR + 2) * CW + 31) / 32 * 32;
+    const int CW = (SW + 2 * PP_DIL + 7) / 8 * 8, NPIX = ((TR + 2 * PP_DIL) * CW + 31) / 32 * 32;
     if (TR < 1 || p.g.SW != SW || p.g.CW != CW || p.g.npix_max != NPIX) return false;
     int nas = 0;
     switch (cfg) {
@@ -830,6 +953,7 @@ bool igemm_pp_supports(int cfg, const IgFwdParams& p) {
     }
     return pp_geo_ok(TM, p.lsw, nas);
 }
+#if PP_DIL == 1
 // (PT = 4: whole rows per wave at widths 16 and 32; PT = 2: at width 16 -- igemm_pp_kernel POOL_OK)
 int igemm_pp_pool_lsw_mask(int cfg) {
     switch (cfg) {
@@ -838,6 +962,7 @@ int igemm_pp_pool_lsw_mask(int cfg) {
     }
     return 0;
 }
+#endif
 // 3x3 taps, stride 1 only (forward and backward-data of the conv3x3 layers)
 hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st) {
     if (p.stride != 1 || p.ostride != 1) return hipErrorInvalidValue;
@@ -862,3 +987,35 @@ hipError_t igemm_pp_launch(int cfg, const IgFwdParams& p, int gx, hipStream_t st
     }
     return hipErrorInvalidValue;
 }
+
+#if PP_DIL == 1
+// ---- split-K support (host)
+static void pp_cfg_dims(int cfg, int& WCO, int& WPX, int& CT, int& PT) {
+    WCO = WPX = CT = PT = 0;
+    switch (cfg) {
+#define PP_CASE(C) case C: WCO = PpCfg<C>::WCO; WPX = PpCfg<C>::WPX; CT = PpCfg<C>::CT; PT = PpCfg<C>::PT; break;
+        PP_CASE(IGF2_CFG_128x256) PP_CASE(IGF2_CFG_64x512) PP_CASE(IGF2_CFG_128x128) PP_CASE(IGF2_CFG_64x256)
+        PP_CASE(IGF2_CFG_128x192) PP_CASE(IGF2_CFG_64x384)
+#undef PP_CASE
+    }
+}
+size_t igemm_pp_slab_floats(int cfg, const IgFwdParams& p) {
+    const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
+    return (size_t)p.N * p.g.nstrips * p.g.tiles_per_strip * p.ncob * ci.TN * ci.TM;
+}
+hipError_t igemm_pp_finish_launch(int cfg, const IgFwdParams& p, hipStream_t st) {
+    PpFinishParams q;
+    memset(&q, 0, sizeof(q));
+    pp_cfg_dims(cfg, q.WCO, q.WPX, q.CT, q.PT);
+    if (!q.CT || p.ksplit < 2 || !p.kslab) return hipErrorInvalidValue;
+    q.slab = p.kslab; q.slice_stride = p.kslab_stride; q.ksplit = p.ksplit;
+    q.nslots = p.N * p.g.nstrips * p.g.tiles_per_strip * p.ncob; q.ncob = p.ncob;
+    q.lsw = p.lsw; q.TR = (q.WPX * q.PT * 16) >> p.lsw;
+    q.nstrips = p.g.nstrips; q.tiles_per_strip = p.g.tiles_per_strip;
+    q.out = p.out; q.mask_src = p.mask_src;
+    q.Ho = p.Ho; q.Wo = p.Wo; q.oH = p.oH; q.oW = p.oW; q.outC = p.outC; q.Cout = p.Cout; q.relu = p.relu;
+    const long threads = (long)q.nslots * 8 * (q.CT / 2) * q.PT * 64;
+    hipLaunchKernelGGL(k_pp_splitk_finish, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, q);
+    return hipGetLastError();
+}
+#endif   // PP_DIL == 1

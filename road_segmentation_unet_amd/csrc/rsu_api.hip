@@ -418,7 +418,36 @@ extern "C" int rsu_dropout_fwd(const void* x, void* y, long n, float keep, unsig
 // igemm_fwd family
 // ---------------------------------------------------------------------------------------------
 // second-generation kernel: persistent workgroups (one per CU); pick the tile shape with the smallest estimated time
-struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; double cost; };
+struct Fwd2Plan { int cfg; TileGeo g; int ncob, grid_x, lsw; double cost; int ksplit, cob_group; };
+// How many (channel block, reduction slice) units of one pixel tile sit on neighbouring workgroup ids (IgFwdParams::cob_group): the 8 XCDs
+// each run a contiguous range of ids through their own L2, so the estimate is the bytes an XCD's run pulls in -- its distinct weight
+// slices plus the halo chunks of its distinct (pixel tile, slice) pairs -- and the divisor of the unit count with the smallest sum wins.
+// Layers with few pixels and many channels (the deep levels) end up with one or two weight slices per XCD, the full-resolution layers
+// with all channel blocks of a tile together as in rounds 1-3.
+static int pick_cob_group(int grid, int ncob, int ksplit, int TN, int ktot, int npix_halo, int nchunks) {
+    const int force = env_int("RSU_COB_GROUP", -1);
+    const int nck = ncob * ksplit;
+    if (force >= 0) return (force > 0 && nck % force == 0) ? force : 0;
+    const int tstride = grid / nck;
+    if (tstride < 1) return 0;
+    const double q = grid / 8.0;
+    const double w_unit = (double)TN * ktot * 2.0 / ksplit, h_pair = (double)npix_halo * 64.0 * nchunks / ksplit;
+    double best = 1e300;
+    int best_a = 0;
+    for (int a = 1; a <= nck; ++a) {
+        if (nck % a || (a > ncob && a % ncob) || (a < ncob && ncob % a)) continue;
+        const double groups = std::max(1.0, std::ceil(q / ((double)a * tstride)));
+        const double units = std::min((double)nck, a * groups);
+        const double tiles = std::min((double)tstride, std::ceil(q / a));
+        const double slices = std::max(1.0, std::ceil(units / ncob));
+        const double fill = units * w_unit + tiles * slices * h_pair;
+        if (fill < best * 0.98) {   // (ties: the smaller group, i.e. fewer distinct weight slices)
+            best = fill;
+            best_a = a;
+        }
+    }
+    return best_a == nck ? 0 : best_a;
+}
 static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
                       int force_cfg, bool shared_chip = false, bool pool = false) {
     double best_cost = 1e300;
@@ -463,6 +492,7 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
         const double eff = ptw <= 2 ? (double)env_int("RSU_PLAN_PT2_PCT", 150) / 100.0
                                     : (ptw == 3 ? (double)env_int("RSU_PLAN_PT3_PCT", 120) / 100.0 : (ptw >= 5 ? 0.96 : 1.0));
         const double cost = nrounds * ((double)ci.TM * ci.TN * eff + ovh);
+        const int nchunks = ktot / (32 * ntap);
         if (cost < best_cost) {
             best_cost = cost;
             best.cfg = cfg;
@@ -471,24 +501,78 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
             best.grid_x = (int)(workers * ncob);
             best.lsw = lsw;
             best.cost = cost;
+            best.ksplit = 1;
+            best.cob_group = (ntap == 9 && stride == 1 && dil == 1 && gy == 1) ? pick_cob_group(best.grid_x, ncob, 1, ci.TN, ktot, g.npix_max, nchunks) : 0;
             have = true;
         }
     }
     return have;
 }
 
+// (the ping-pong kernel of the launch's dilation: igemm_pp.hip / igemm_pp_d2.hip)
+static bool pp_supports(int cfg, const IgFwdParams& p) { return p.dil == 2 ? igemm_pp_d2_supports(cfg, p) : igemm_pp_supports(cfg, p); }
+// Split-K plan of a 3x3 stride-1 launch, or false. A PURE FUNCTION OF THE LAYER'S GEOMETRY (never of the CU budget, the tuning table or
+// a measurement), so that the same layer sums its reduction in the same order in every schedule, on every box: results stay repeatable bit
+// for bit across one / two streams and tuned / untuned runs. Rule: with P = (pixel tiles) x (128-channel blocks) of the 128x256 shape, or
+// failing that of the 128x128 shape, a layer with P <= 128 cuts its reduction into S = min(256 / P, chunks / 4, 16) >= 2 slices of at least
+// four 32-channel chunks; the launch then has P x S workgroups of ONE tile slice each (the hardware deals them over the CUs; a launch
+// planned for half the chip simply takes two turns), followed by the finish launch. Needs S x P x (tile floats) of workspace.
+static bool plan_split(Fwd2Plan& pl, int N, int Ho, int Wo, int Cout, int ktot, size_t kws_floats, int dil = 1) {
+    if (kws_floats == 0 || Cout < 128 || env_int("RSU_KSPLIT", 1) == 0 || env_int("RSU_FWD_GEN", 3) < 3 || env_int("RSU_FWD2_CFG", -1) >= 0) return false;
+    const int nchunks = ktot / (32 * 9);
+    const int cands[2] = {IGF2_CFG_128x256, IGF2_CFG_128x128};
+    for (int k = 0; k < 2; ++k) {
+        const int cfg = cands[k];
+        const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
+        const long fixed = (long)igemm_fwd2_lds_bytes(cfg, 9, 0);
+        const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, 9, 1) - fixed;
+        int cap = (int)((160 * 1024 - fixed) / per_pix);
+        const int cap2 = igemm_fwd2_max_pieces(cfg, 9) * 16;
+        if (cap2 < cap) cap = cap2;
+        TileGeo g;
+        int lsw = 0;
+        if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, 3, 3, dil, 1, cap)) continue;
+        const int ncob = cdiv(Cout, ci.TN);
+        const long P = (long)N * g.nstrips * g.tiles_per_strip * ncob;
+        if (P > 128) continue;
+        int S = (int)(256 / P);
+        if (S > nchunks / 4) S = nchunks / 4;
+        if (S > 16) S = 16;
+        if (S < 2) continue;
+        if (k == 0 && P * S < 192 && nchunks / 4 > S) continue;   // (the smaller tiles fill the chip better: see whether they split too)
+        if ((size_t)S * (size_t)P * ci.TM * ci.TN > kws_floats) continue;
+        {   // ... and the ping-pong kernel must be instantiated for this geometry
+            IgFwdParams t;
+            memset(&t, 0, sizeof(t));
+            t.stride = t.ostride = 1; t.dil = dil; t.lsw = lsw; t.g = g; t.ksplit = S; t.kslab = (float*)16;
+            if (!pp_supports(cfg, t)) continue;
+        }
+        pl.cfg = cfg; pl.g = g; pl.ncob = ncob; pl.lsw = lsw; pl.ksplit = S;
+        pl.grid_x = (int)(P * S);
+        pl.cost = ((double)ci.TM * ci.TN * (k ? 1.5 : 1.0) / S + 4096.0) * (double)cdiv((int)(P * S), 256);
+        pl.cob_group = pick_cob_group(pl.grid_x, ncob, S, ci.TN, ktot, g.npix_max, nchunks);
+        return true;
+    }
+    return false;
+}
+
 // persistent conv launch of the chosen generation: the ping-pong kernel (igemm_pp.hip) runs the 3x3 stride-1 launches unless
 // RSU_FWD_GEN=2 asks for igemm_fwd2 (same tile shapes, same bits)
 // (pp: 0 = igemm_fwd2, 1 = igemm_pp)
 static hipError_t launch_persistent(int pp, int cfg, int ntap, const IgFwdParams& p, int gx, int gy, hipStream_t st) {
-    if (pp && igemm_pp_supports(cfg, p)) return igemm_pp_launch(cfg, p, gx, st);
+    if (pp && pp_supports(cfg, p)) {
+        hipError_t e = p.dil == 2 ? igemm_pp_d2_launch(cfg, p, gx, st) : igemm_pp_launch(cfg, p, gx, st);
+        if (e == hipSuccess && p.ksplit > 1) e = igemm_pp_finish_launch(cfg, p, st);   // split-K: the slices' partial sums -> bf16 output
+        return e;
+    }
+    if (p.ksplit > 1) return hipErrorInvalidValue;   // (only the ping-pong kernel splits its reduction)
     return igemm_fwd2_launch(cfg, ntap, p, gx, gy, st);
 }
 
 static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_stride, int ntiles_w, int tile_off, const float* bias,
                    void* out, const void* mask_src, int N, int Hin, int Win, int Ho, int Wo, int Cout, int outC, int ntap, int kw,
                    int dil, int stride, int pad, int oH, int oW, int ostride, int gy, int relu, int accumulate, int ncu_arg, hipStream_t st,
-                   void* pool_out = nullptr, void* pool_code = nullptr) {
+                   void* pool_out = nullptr, void* pool_code = nullptr, float* kws = nullptr, size_t kws_floats = 0) {
     const int kh = ntap / kw;
     const bool pool = pool_out != nullptr;
     const int ncu = launch_ncu(ncu_arg);
@@ -500,7 +584,7 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     if (out_bytes >= 0x7ffffff0L) return RSU_E2BIG;
     // RSU_FWD_GEN: 2 = igemm_fwd2 only; 3 (default) = the ping-pong kernel where it measured (or, untuned, is expected to be) faster;
     // 4 = the ping-pong kernel wherever it is built (tests)
-    const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1 && dil == 1;
+    const bool pp_ok = gen >= 3 && ntap == 9 && stride == 1 && ostride == 1 && gy == 1 && (dil == 1 || (dil == 2 && env_int("RSU_PP_DIL2", 1) != 0));
     for (int i = 0; i < nsrc; ++i)
         if ((long)N * srcs[i].H * srcs[i].W * srcs[i].C * 2 >= 0x7ffffff0L) return RSU_E2BIG;
     Fwd2Plan pl2;
@@ -511,11 +595,16 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
     const int tune_mode = env_int("RSU_AUTOTUNE", 1) != 0 ? g_autotune.load() : RSU_TUNE_OFF;
     const bool tunable = env_cfg < 0 && !accumulate && tune_mode != RSU_TUNE_OFF;
+    (void)0;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
                                 (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (pool ? 8 : 0) | (pool_code ? 16 : 0), ostride, ncu * 8 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
+    if (!kws || accumulate) kws_floats = 0;
+    // split-K: decided from the geometry alone (plan_split), outside the tuning table
+    Fwd2Plan pls;
+    const bool split = pp_ok && !pool && kws_floats > 0 && plan_split(pls, N, Ho, Wo, Cout, ktot, kws_floats, dil);
     bool tune_now = false;
-    if (tunable) {
+    if (tunable && !split) {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         auto it = g_tuned.find(tkey);
         if (it != g_tuned.end()) {
@@ -525,7 +614,9 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
             tune_now = tune_mode == RSU_TUNE_MEASURE;
         }
     }
-    if (!plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip, pool)) {
+    if (split) {
+        pl2 = pls;
+    } else if (!plan_fwd2(pl2, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, tuned_cfg >= 0 ? tuned_cfg : env_cfg, shared_chip, pool)) {
         // a shape forced through RSU_FWD2_CFG, or a tuned shape (an imported table), whose halo tile does not fit this geometry: plan
         // freely instead (and forget the table entry)
         if (tuned_cfg >= 0) {
@@ -569,11 +660,19 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     {
         // kernel generation: the ping-pong kernel wherever it is instantiated (measured 10-20 % faster than igemm_fwd2 at every
         // shape; launch_persistent falls back to igemm_fwd2 for the rest) unless the tuner measured otherwise for this geometry
-        const int pp = (pp_ok && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0 || pool)) ? 1 : 0;
+        const int pp = (pp_ok && !accumulate && igemm_pp_has(pl2.cfg) && (gen >= 4 || tuned_pp != 0 || pool || pl2.ksplit > 1)) ? 1 : 0;
         if (pool && !pp) return RSU_EINVAL;
-        p.ncob = pl2.ncob;
-        p.g = pl2.g;
-        p.lsw = pl2.lsw;
+        auto apply_plan = [&](IgFwdParams& q, const Fwd2Plan& pl) {
+            q.ncob = pl.ncob;
+            q.g = pl.g;
+            q.lsw = pl.lsw;
+            q.ksplit = pl.ksplit;
+            q.cob_group = pl.cob_group;
+            q.kslab = pl.ksplit > 1 ? kws : nullptr;
+            q.kslab_stride = pl.ksplit > 1 ? (long)igemm_pp_slab_floats(pl.cfg, q) : 0;
+        };
+        apply_plan(p, pl2);
+        if (p.ksplit > 1 && (!pp || (size_t)p.ksplit * (size_t)p.kslab_stride > kws_floats)) return RSU_EINVAL;
 #ifdef RSU_DEV_KERNELS   // developer build only: timing ablations and the time-stamping kernels (the default build ignores these variables)
         p.dbg = env_int("RSU_FWD_DBG", 0);
         if (p.dbg & 128) {
@@ -584,14 +683,14 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
         if (env_int("RSU_PLAN_DEBUG", 0)) {
             const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(pl2.cfg);
             const long tiles = (long)N * pl2.g.nstrips * pl2.g.tiles_per_strip;
-            const long workers = pl2.grid_x / pl2.ncob;
+            const long workers = pl2.grid_x / (pl2.ncob * pl2.ksplit);
             const long rounds = (tiles + workers - 1) / workers;
-            fprintf(stderr, "[plan fwd2] N%d %dx%d Cout%d ntap%d pad%d: cfg%d TN%d TM%d SW%d strips%d tps%d halo%d tiles%ld grid%d rounds%ld pix_util %.3f total_util %.3f\n",
+            fprintf(stderr, "[plan fwd2] N%d %dx%d Cout%d ntap%d pad%d: cfg%d TN%d TM%d SW%d strips%d tps%d halo%d tiles%ld grid%d rounds%ld ksplit%d cgrp%d pix_util %.3f total_util %.3f\n",
                     N, Ho, Wo, Cout, ntap, pad, pl2.cfg, ci.TN, ci.TM, pl2.g.SW, pl2.g.nstrips, pl2.g.tiles_per_strip, pl2.g.npix_max, tiles,
-                    pl2.grid_x, rounds, (double)N * Ho * Wo / ((double)tiles * ci.TM),
-                    (double)N * Ho * Wo * Cout / ((double)rounds * pl2.grid_x * ci.TM * ci.TN));
+                    pl2.grid_x, rounds, pl2.ksplit, pl2.cob_group, (double)N * Ho * Wo / ((double)tiles * ci.TM),
+                    (double)N * Ho * Wo * Cout / ((double)rounds * pl2.grid_x * ci.TM * ci.TN) * pl2.ksplit);
         }
-        if (tune_now) {
+        if (tune_now && !split) {
             // time every admissible shape of the same channel-block width (1 untimed + 5 timed launches each, fastest counts, device idle; the
             // launches all write the same values, so the output is valid whichever ran last)
             const int tn_model = igemm_fwd2_cfg_info(pl2.cfg).TN;
@@ -614,13 +713,11 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
                 Fwd2Plan pc;
                 if (!plan_fwd2(pc, ncu, N, Ho, Wo, Cout, ntap, kh, kw, dil, stride, gy, ktot, cfg, shared_chip, pool)) continue;
                 IgFwdParams pt = p;
-                pt.ncob = pc.ncob;
-                pt.g = pc.g;
-                pt.lsw = pc.lsw;
+                apply_plan(pt, pc);
                 for (int vpp = 0; vpp < 2; ++vpp) {  // the kernel generations of the shape
-                    if (vpp == 1 && !(pp_ok && igemm_pp_supports(cfg, pt))) continue;
+                    if (vpp == 1 && !(pp_ok && !accumulate && pp_supports(cfg, pt))) continue;
                     if (vpp == 0 && pool) continue;   // (only the ping-pong kernel folds the pool)
-                    if (!vpp && gen >= 4 && pp_ok && igemm_pp_supports(cfg, pt)) continue;
+                    if (!vpp && gen >= 4 && pp_ok && !accumulate && pp_supports(cfg, pt)) continue;
                     float ms_min = 1e30f;
                     for (int rep = 0; rep < 6; ++rep) {
                         HIP_CHECK_RET(hipEventRecord(e0, st));
@@ -653,17 +750,30 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     }
 }
 
-extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
-                              int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream) {
+// workspace a launch needs before it may cut its reduction into slices (split-K): room for one fp32 copy of the padded output per slice on
+// a chip's worth of workgroups -- 256 workgroups x the largest accumulator tile (128 x 256 floats)
+extern "C" size_t rsu_conv_splitk_ws_floats(void) { return (size_t)256 * 128 * 256 + 1024; }
+extern "C" int rsu_conv2d_fwd_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
+                                int Win, int Cout, int dil, int relu, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream) {
     if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || Cout % 8 || (dil != 1 && dil != 2)) return RSU_EINVAL;
     const int Ho = Hin - 2 * dil, Wo = Win - 2 * dil;
     if (Ho < 1 || Wo < 2) return RSU_EINVAL;
     return run_fwd(srcs, nsrc, packed_fwd, 0, rup(Cout, 128) / 16, 0, bias, y, nullptr, N, Hin, Win, Ho, Wo, Cout, Cout, 9, 3, dil, 1, 0,
-                   Ho, Wo, 1, 1, relu, 0, ncu, (hipStream_t)stream);
+                   Ho, Wo, 1, 1, relu, 0, ncu, (hipStream_t)stream, nullptr, nullptr, kws, kws_floats);
+}
+extern "C" int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N, int Hin,
+                              int Win, int Cout, int dil, int relu, int ncu, rsu_stream_t stream) {
+    return rsu_conv2d_fwd_k(srcs, nsrc, packed_fwd, bias, y, N, Hin, Win, Cout, dil, relu, ncu, nullptr, 0, stream);
 }
 
+extern "C" int rsu_conv2d_fwd_pool_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
+                                     int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
 extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
                                    int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, rsu_stream_t stream) {
+    return rsu_conv2d_fwd_pool_k(srcs, nsrc, packed_fwd, bias, y, pooled, code, N, Hin, Win, Cout, keep, key, ncu, nullptr, 0, stream);
+}
+extern "C" int rsu_conv2d_fwd_pool_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
+                                     int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream) {
     if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !pooled || Cout % 8 || !keep_ok(keep)) return RSU_EINVAL;
     const int Ho = Hin - 2, Wo = Win - 2;
     if (Ho < 2 || Wo < 2) return RSU_EINVAL;
@@ -680,7 +790,9 @@ extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* 
         int ktot = 0;
         for (int i = 0; i < nsrc; ++i) ktot += rup(srcs[i].C, 32) * 9;
         (void)kt;
-        worth = n > 0 && plan_fwd2(a, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, false) &&
+        Fwd2Plan sp;
+        worth = n > 0 && !(kws && plan_split(sp, N, Ho, Wo, Cout, ktot, kws_floats)) &&   // (a layer that splits its reduction does not fold the pool)
+                plan_fwd2(a, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, false) &&
                 plan_fwd2(b, n, N, Ho, Wo, Cout, 9, 3, 3, 1, 1, 1, ktot, -1, false, true) && b.cost <= 1.08 * a.cost;
     }
     if (keep == 1.f && even && worth && env_int("RSU_FWD_GEN", 3) >= 3 && env_int("RSU_FWD2_CFG", -1) < 0) {
@@ -688,7 +800,7 @@ extern "C" int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* 
                                1, 1, 1, 0, ncu, (hipStream_t)stream, pooled, code);
         if (rc != RSU_EINVAL) return rc;
     }
-    const int rc = rsu_conv2d_fwd(srcs, nsrc, packed_fwd, bias, y, N, Hin, Win, Cout, 1, 1, ncu, stream);
+    const int rc = rsu_conv2d_fwd_k(srcs, nsrc, packed_fwd, bias, y, N, Hin, Win, Cout, 1, 1, ncu, kws, kws_floats, stream);
     if (rc != RSU_OK) return rc;
     return rsu_maxpool2x2_fwd_code(y, pooled, code, N, Ho, Wo, Cout, keep, key, stream);
 }
@@ -718,8 +830,14 @@ extern "C" int rsu_conv_first_fwd(const void* in16, const void* packed, const fl
                    ncu, (hipStream_t)stream);
 }
 
+extern "C" int rsu_conv2d_bwd_data_k(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
+                                     int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
 extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
                                    int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, rsu_stream_t stream) {
+    return rsu_conv2d_bwd_data_k(dz, packed_bwd, dx, relu_src, accumulate, N, H, W, Cin_total, ci_off, ci_cnt, Cout, dil, ncu, nullptr, 0, stream);
+}
+extern "C" int rsu_conv2d_bwd_data_k(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
+                                     int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream) {
     if (!dz || !packed_bwd || !dx || Cout % 8 || ci_cnt % 8 || ci_off % 32 || ci_off + ci_cnt > Cin_total || (dil != 1 && dil != 2))
         return RSU_EINVAL;
     const int Hd = H - 2 * dil, Wd = W - 2 * dil;  // dz size
@@ -727,7 +845,7 @@ extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void*
     rsu_src_t s;
     s.ptr = dz; s.H = Hd; s.W = Wd; s.C = Cout; s.oy = 0; s.ox = 0;
     return run_fwd(&s, 1, packed_bwd, 0, rup(Cin_total, 128) / 16, ci_off / 16, nullptr, dx, relu_src, N, Hd, Wd, H, W, ci_cnt, ci_cnt, 9,
-                   3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, ncu, (hipStream_t)stream);
+                   3, dil, 1, 2 * dil, H, W, 1, 1, 0, accumulate, ncu, (hipStream_t)stream, nullptr, nullptr, kws, kws_floats);
 }
 
 // igemm_ct launch (transposed conv forward / backward-data as a ping-pong GEMM): one workgroup per budgeted CU, column blocks fastest

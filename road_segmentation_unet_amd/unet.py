@@ -234,6 +234,11 @@ class UNet:
         self.logits = torch.zeros((B, self.P, self.P, 2), dtype=torch.float32, device=dev)
         self.labels = torch.zeros((B, self.P, self.P), dtype=torch.int64, device=dev)
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        # workspace of the conv launches that cut their reduction into slices (rsu.h rsu_conv2d_fwd_k: the deep levels at small batches);
+        # one per stream that issues conv launches -- the main stream, and the side stream of the dilated twin blocks in the forward pass
+        nk = int(_lib.lib().rsu_conv_splitk_ws_floats()) if os.environ.get("RSU_KSPLIT", "1") != "0" else 0
+        self.kws = torch.zeros(nk, dtype=torch.float32, device=dev) if nk else None
+        self.kws_side = torch.zeros(nk, dtype=torch.float32, device=dev) if (nk and self.dilated and self.wstreams) else None
         if self.training:
             for k, t in self.act.items():
                 if k.startswith("up_") or k.startswith("c") or k.startswith("d") or k.startswith("pool_"):
@@ -458,9 +463,19 @@ class UNet:
         cout = out.shape[3]
         cin = sum(s.C for s in srcs)
         ho = hin - 2 * dil
-        self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd", arr, len(srcs),
+        kws = self._kws()
+        self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd_k", arr, len(srcs),
                     _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
-                    self._ncu, self._stream())
+                    self._ncu, _ptr(kws), kws.numel() if kws is not None else 0, self._stream())
+
+    def _kws(self):
+        """the split-K workspace of the stream the next conv launch goes to (None: that launch never splits)"""
+        if self.kws is None or not self.wstreams:
+            return self.kws
+        cur = torch.cuda.current_stream(self.device)
+        if cur == self.wstreams[0]:
+            return self.kws_side
+        return self.kws if all(cur != s for s in self.wstreams) else None
 
     def _conv_first(self, name, out, h, dil, st):
         call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
@@ -503,9 +518,11 @@ class UNet:
                 c1, c2 = a["c1_%d" % i], a["c2_%d" % i]
                 nf_ = c2.shape[3]
                 src = (RsuSrc * 1)(_src(c1, h - 2, h - 2))
-                self._timed("conv3x3_fwd", 2.0 * B * (h - 4) * (h - 4) * nf_ * c1.shape[3] * 9, "rsu_conv2d_fwd_pool", src, 1,
+                kws = self._kws()
+                self._timed("conv3x3_fwd", 2.0 * B * (h - 4) * (h - 4) * nf_ * c1.shape[3] * 9, "rsu_conv2d_fwd_pool_k", src, 1,
                             _ptr(self.pk["conv_%d/conv2/kernel" % i, "fwd"]), _ptr(self.w["conv_%d/conv2/bias" % i]), _ptr(c2),
-                            _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 2, h - 2, nf_, keep, self.dropout_key(i + 1), self._ncu, st)
+                            _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 2, h - 2, nf_, keep, self.dropout_key(i + 1), self._ncu,
+                            _ptr(kws), kws.numel() if kws is not None else 0, st)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
         if self.dilated:
@@ -621,9 +638,10 @@ class UNet:
         cout = self.w[name + "/kernel"].shape[3]
         cnt = dx.shape[3]
         ho = hin - 2 * dil
-        self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data", _ptr(dz),
+        kws = self._kws()
+        self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data_k", _ptr(dz),
                     _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
-                    cout, dil, self._ncu, self._stream())
+                    cout, dil, self._ncu, _ptr(kws), kws.numel() if kws is not None else 0, self._stream())
 
     def backward_device(self, inv_count):
         """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count)."""

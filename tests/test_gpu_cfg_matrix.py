@@ -146,14 +146,15 @@ def test_conv3x3_bwd_weight_both_shapes(wg_cfg, N, H, W, Cin, Cout, dil):
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
-def test_pingpong_kernel_gives_the_bits_of_igemm_fwd2(cfg):
-    """igemm_pp keeps igemm_fwd2's summation order: forward and masked backward-data agree bit for bit, shape by shape."""
+@pytest.mark.parametrize("dil", [1, 2])
+def test_pingpong_kernel_gives_the_bits_of_igemm_fwd2(cfg, dil):
+    """igemm_pp (dilation 2: igemm_pp_d2.hip) keeps igemm_fwd2's summation order: forward and masked backward-data agree bit for bit, shape by shape."""
     rng = np.random.RandomState(7 + cfg)
     N, H, W, Cin, Cout = 2, 90, 84, 96, 128
     x = hu.q(_rand(rng, N, H, W, Cin))
     w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
     b = _rand(rng, Cout, scale=0.1)
-    dz = hu.q(_rand(rng, N, H - 2, W - 2, Cout, scale=0.1))
+    dz = hu.q(_rand(rng, N, H - 2 * dil, W - 2 * dil, Cout, scale=0.1))
     xd, wp, bd, dzd, wb = hu.dev_bf16(x), hu.pack_conv_fwd(w), hu.dev_f32(b), hu.dev_bf16(dz), hu.pack_conv_bwd(w, 0, Cin)
     s = (RsuSrc * 1)(hu.src_of(xd, H, W))
     old = {k: os.environ.get(k) for k in ("RSU_FWD2_CFG", "RSU_FWD_GEN")}
@@ -162,10 +163,10 @@ def test_pingpong_kernel_gives_the_bits_of_igemm_fwd2(cfg):
         os.environ["RSU_FWD2_CFG"] = str(cfg)
         for gen in (2, 4):
             os.environ["RSU_FWD_GEN"] = str(gen)
-            y = torch.full((N, H - 2, W - 2, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+            y = torch.full((N, H - 2 * dil, W - 2 * dil, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
             dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
-            call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, 1, 1, 0, hu.stream())
-            call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), hu.ptr(xd), 0, N, H, W, Cin, 0, Cin, Cout, 1, 0, hu.stream())
+            call("rsu_conv2d_fwd", s, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, dil, 1, 0, hu.stream())
+            call("rsu_conv2d_bwd_data", hu.ptr(dzd), hu.ptr(wb), hu.ptr(dx), hu.ptr(xd), 0, N, H, W, Cin, 0, Cin, Cout, dil, 0, hu.stream())
             out[gen] = (y.view(torch.int16).cpu().numpy().copy(), dx.view(torch.int16).cpu().numpy().copy())
     finally:
         for k, v in old.items():

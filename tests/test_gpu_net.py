@@ -273,8 +273,11 @@ def test_c2_benchmarked_batch_of_four_equals_one_patch(wgrad_stream, monkeypatch
     l4, g4, p4 = run(4, X4, lab4, True)
     l1, g1, p1 = run(1, X1, lab1, False)
     assert abs(l4 - l1) <= 1e-5 * abs(l1), (l4, l1)
-    for b in range(4):   # every image of the batch sees the arithmetic of the single patch: the forward pass is bit-identical
-        np.testing.assert_array_equal(p4[b], p1[0])
+    for b in range(4):
+        # every image of the batch sees the arithmetic of the single patch up to the split of the deep layers' reductions (rsu.h
+        # rsu_conv2d_fwd_k: B = 1 cuts them into more slices than B = 4): rounding-boundary flips of single bf16 activations
+        np.testing.assert_array_equal(p4[b], p4[0])
+        assert float(np.abs(p4[b] - p1[0]).max()) <= 2e-3, float(np.abs(p4[b] - p1[0]).max())
     worst = ("", 0.0)
     for n in g4:
         assert np.isfinite(g4[n]).all() and np.abs(g4[n]).max() > 0, n

@@ -87,6 +87,79 @@ def test_conv2d_fwd_odd_channel_segments():
     hu.assert_bf16_close(hu.host(y), ref, "conv2d_fwd 16+16")
 
 
+# ------------------------------------------------------------------------------------------- split-K (rsu_conv2d_*_k)
+def _plan_lines(capfd):
+    return [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("[plan fwd2]")]
+
+
+SPLITK_SHAPES = [
+    # N, H, W, srcs (channels), Cout: few pixels, long reductions -- the deep levels of configs 3 / 4 at one patch per step
+    (1, 20, 20, [512], 512),
+    (1, 22, 18, [256, 256, 128], 256),   # three concat sources, a slice boundary inside a source and slices that start in the 2nd / 3rd
+    (2, 12, 12, [1024], 256),
+    (1, 20, 20, [200, 120], 128),        # sources that are not multiples of 32 channels (partial last chunks inside slices)
+]
+
+
+@pytest.mark.parametrize("N,H,W,segs,Cout", SPLITK_SHAPES)
+def test_conv2d_fwd_split_k(N, H, W, segs, Cout, capfd, monkeypatch):
+    """rsu_conv2d_fwd_k with a workspace: the planner cuts the reduction of these few-pixel layers into slices (checked on its debug
+    line), the finish launch sums them in slice order -> against the oracle (the op tolerance) and against the unsplit launch (equal up to
+    the association of one fp32 sum: at most a rounding-boundary flip of 1 bf16 ulp), repeatable bit for bit"""
+    monkeypatch.setenv("RSU_PLAN_DEBUG", "1")
+    rng = np.random.RandomState(H * 7 + Cout + len(segs))
+    Cin = sum(segs)
+    xs = [hu.q(_rand(rng, N, H, W, c)) for c in segs]
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    xds = [hu.dev_bf16(x) for x in xs]
+    wp = hu.pack_conv_fwd(w, segs if len(segs) > 1 else None)
+    bd = hu.dev_f32(b)
+    Ho, Wo = H - 2, W - 2
+    srcs = (RsuSrc * len(segs))(*[hu.src_of(xd, H, W) for xd in xds])
+    nk = int(lib().rsu_conv_splitk_ws_floats())
+    kws = torch.full((nk,), float("nan"), dtype=torch.float32, device=hu.DEV)
+    outs = []
+    for rep in range(2):
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        capfd.readouterr()
+        call("rsu_conv2d_fwd_k", srcs, len(segs), hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, W, Cout, 1, 1, 0, hu.ptr(kws), nk, hu.stream())
+        lines = _plan_lines(capfd)
+        assert lines and " ksplit1 " not in lines[-1], lines   # the launch did split
+        outs.append(hu.host(y))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    ref = U.conv2d_fwd(np.concatenate(xs, axis=3), hu.q(w), b, relu=True)
+    hu.assert_bf16_close(outs[0], ref, "conv2d_fwd split-K")
+    y1 = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_conv2d_fwd", srcs, len(segs), hu.ptr(wp), hu.ptr(bd), hu.ptr(y1), N, H, W, Cout, 1, 1, 0, hu.stream())
+    hu.assert_bf16_close(outs[0], hu.host(y1).astype(np.float64), "split-K vs unsplit", ulps=1.0)
+    assert (outs[0] != hu.host(y1)).mean() < 0.05
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 20, 20, 512, 512), (2, 14, 14, 256, 1024)])
+def test_conv2d_bwd_data_split_k(N, H, W, Cin, Cout, capfd, monkeypatch):
+    """rsu_conv2d_bwd_data_k: split reduction with the ReLU mask applied by the finish launch"""
+    monkeypatch.setenv("RSU_PLAN_DEBUG", "1")
+    rng = np.random.RandomState(Cin + Cout * 3 + W)
+    Ho, Wo = H - 2, W - 2
+    dz = hu.q(_rand(rng, N, Ho, Wo, Cout))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cout))
+    yprev = hu.q(np.maximum(_rand(rng, N, H, W, Cin), 0))
+    wp = hu.pack_conv_bwd(w)
+    dzd, yd = hu.dev_bf16(dz), hu.dev_bf16(yprev)
+    nk = int(lib().rsu_conv_splitk_ws_floats())
+    kws = torch.full((nk,), float("nan"), dtype=torch.float32, device=hu.DEV)
+    for mask in (yd, None):
+        dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        capfd.readouterr()
+        call("rsu_conv2d_bwd_data_k", hu.ptr(dzd), hu.ptr(wp), hu.ptr(dx), hu.ptr(mask) if mask is not None else None, 0, N, H, W, Cin, 0, Cin, Cout, 1, 0,
+             hu.ptr(kws), nk, hu.stream())
+        lines = _plan_lines(capfd)
+        assert lines and " ksplit1 " not in lines[-1], lines
+        g = U.conv2d_bwd_data(dz, hu.q(w), (H, W))
+        hu.assert_bf16_close(hu.host(dx), U.relu_bwd(yprev, g) if mask is not None else g, "conv2d_bwd_data split-K")
+
+
 # ------------------------------------------------------------------------------------------- conv backward data
 @pytest.mark.parametrize("N,H,W,Cin,Cout,dil", CONV_SHAPES[:6])
 def test_conv2d_bwd_data(N, H, W, Cin, Cout, dil):

@@ -307,7 +307,11 @@ def test_config4_share_full_size_training_step_properties():
     assert abs(losses[0][0] - np.log(2.0)) < 0.3          # Glorot weights: the first loss sits near ln 2
 
 
-def test_config5_full_size_sliding_window():
+def test_config5_full_size_sliding_window(monkeypatch):
+    # (the tiles of a shared window and of the per-tile pass are the same bits only while every layer sums its reduction in the same
+    # order in both: the geometry-dependent split of the deep layers' reductions, rsu.h rsu_conv2d_fwd_k, is switched off for this property
+    # test; test_config5_shared_windows_with_split_reductions checks the default path against it by tolerance)
+    monkeypatch.setenv("RSU_KSPLIT", "0")
     L, root, P, H, stride = 6, 64, 388, 604, 12
     rng = np.random.RandomState(51)
     img = rng.rand(1, H, H, 3).astype(np.float32)
@@ -342,3 +346,22 @@ def test_config5_full_size_sliding_window():
     m.net.forward_device()
     got = m.net.prob[0].cpu().numpy()
     assert np.abs(got - emu[0]).max() <= 4e-3
+
+
+def test_config5_shared_windows_with_split_reductions(monkeypatch):
+    """config 5's default inference path (deep layers with split reductions, rsu_conv2d_fwd_k) against the same path without the split:
+    the masks differ by rounding-boundary flips of single bf16 activations only"""
+    L, root, P, H, stride = 6, 64, 388, 604, 12
+    rng = np.random.RandomState(51)
+    img = rng.rand(1, H, H, 3).astype(np.float32)
+    params = U.init_params(L, root, True, seed=52, bias_scale=0.02)
+    masks = {}
+    for ks in ("1", "0"):
+        monkeypatch.setenv("RSU_KSPLIT", ks)
+        m = ConvolutionalModel(Options(num_layers=L, root_size=root, patch_size=P, stride=stride, dilated_layers=True, batch_size=4,
+                                       ensemble_prediction=True, dropout=1.0, logdir=None), params=params)
+        masks[ks] = m.predict(img)
+        del m
+        torch.cuda.empty_cache()
+    d = np.abs(masks["1"] - masks["0"])
+    assert np.isfinite(masks["1"]).all() and d.max() <= 2e-3 and d.mean() <= 1e-4, (float(d.max()), float(d.mean()))
