@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--gens", default="", help="comma list of RSU_FWD_GEN values to time side by side (fwd / bwd ops)")
     ap.add_argument("--dbg", default="", help="comma list of RSU_FWD_DBG values to time side by side")
+    ap.add_argument("--ncu", type=int, default=0, help="CU budget the launches plan for (0: the library default, 256)")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")]
     gens = [g for g in args.gens.split(",") if g] or [None]
@@ -76,6 +77,9 @@ def main():
     ops = args.ops.split(",")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     call("rsu_set_autotune", 2)   # developer tool: measure tile shapes at first sight (RSU_TUNE_MEASURE)
+    nk = int(lib().rsu_conv_splitk_ws_floats())
+    kws = torch.zeros(nk, device=DEV)   # split-K workspace (rsu_conv2d_*_k): the launches may cut their reductions as the product's do
+    ncu = args.ncu
     tot = {}
     for name, hin, cin, cout, dil in layers(args.L, args.root, args.P, args.dilated):
         if args.only and args.only not in name:
@@ -113,17 +117,17 @@ def main():
                     os.environ.pop("RSU_FWD2_CFG", None)
                 try:
                     if op == "fwd":
-                        t = timeit(lambda: call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, 0, st))
+                        t = timeit(lambda: call("rsu_conv2d_fwd_k", arr, 1, ptr(pf), ptr(bias), ptr(y), B, hin, hin, cout, dil, 1, ncu, ptr(kws), nk, st))
                     elif op == "bwd":
-                        t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, 0, st))
+                        t = timeit(lambda: call("rsu_conv2d_bwd_data_k", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, hin, hin, cin, 0, cin, cout, dil, ncu, ptr(kws), nk, st))
                     elif op == "bwdnm":  # backward-data without the ReLU mask (A/B: cost of the mask loads in the epilogue)
-                        t = timeit(lambda: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, 0, st))
+                        t = timeit(lambda: call("rsu_conv2d_bwd_data_k", ptr(dz), ptr(pb), ptr(dx), None, 0, B, hin, hin, cin, 0, cin, cout, dil, ncu, ptr(kws), nk, st))
                     else:  # "wg", or "wg1" / "wg2" = igemm_wgrad / igemm_wgpp (RSU_WG_GEN)
                         if len(op) > 2:  # "wg2d3" = generation 2 with RSU_WG_DBG=3 (timing ablation)
                             g_, _, d_ = op[2:].partition("d")
                             os.environ["RSU_WG_GEN"] = g_
                             os.environ["RSU_WG_DBG"] = d_ or "0"
-                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, 0, st))
+                        t = timeit(lambda: call("rsu_conv2d_bwd_weight", ctypes.byref(src), ptr(dz), ptr(dw), ptr(db), ptr(ws), B, ho, ho, cin, 0, cout, dil, ncu, st))
                     tag = ("" if cfg < 0 else "[%d]" % cfg) + ("" if gen is None else "g" + gen) + ("" if dbg is None else "d" + dbg)
                     line += " %s%s %6.0fus %5.0fTF |" % (op, tag, t * 1e6, fl / t / 1e12)
                     tot[(op, tag)] = tot.get((op, tag), 0.0) + t
