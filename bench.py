@@ -341,8 +341,17 @@ def main():
                   "launches": v[2] // nprof} for k, v in agg.items()}
         return {"achieved": fl / t / 1e12 if t > 0 else 0.0, "by_kernel": by, "launches": n, "chip_s": t, "flops": fl, "label": label}
 
-    # (1) the timed schedule itself: two streams in the backward pass, every launch with the CU share it has there
-    prof_timed = instrumented("timed schedule")
+    # (1) the timed schedule itself: two streams in the backward pass, every launch with the CU share it has there. The conv launches of a
+    # step cannot hold the chip for longer than the step lasts: a pass whose chip time exceeds the timed step by more than 15 % is not a
+    # measurement of that schedule (seen once in ~30 runs on the test pool: both backward queues reported ~6x their usual kernel durations
+    # for one pass, profiles/r04/bench_odd_pass.json) and is repeated, at most twice.
+    attempts = 0
+    while True:
+        attempts += 1
+        prof_timed = instrumented("timed schedule")
+        plausible = prof_timed["chip_s"] / nprof <= 1.15 * dt / args.steps
+        if plausible or attempts >= 3:
+            break
     # (2), (3) serialised single-stream passes, every launch alone on the chip: one weight-gradient launch per layer (rounds 1-2's
     # figure), then the single-stream product schedule with grouped weight gradients (round 3's headline figure)
     wstreams, m.wstreams = m.wstreams, []
@@ -420,6 +429,7 @@ def main():
                                         if two_streams else "one stream, every launch alone on the chip; ")
                                      + "achieved = algorithmic FLOPs / sum over launches of (duration x share of the 256 CUs the launch plans for)"),
                      "kernel": "3x3 conv MFMA kernels: igemm_pp / igemm_fwd2 (forward, backward-data) + igemm_wgpp / igemm_wgrad / igemm_wg_group (weight gradient)",
+                     "timed_schedule_pass": {"attempts": attempts, "plausible": bool(plausible)},
                      "launches_per_step": n_launch // nprof,
                      "avg_launch_us": sum(v["wall_ms_per_step"] for v in prof_timed["by_kernel"].values()) / max(1, n_launch // nprof) * 1e3,
                      "conv_chip_ms_per_step": conv_t / nprof * 1e3,
