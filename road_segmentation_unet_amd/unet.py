@@ -27,6 +27,7 @@ NUM_LABELS = 2    # src/constants.py:4
 _WG_GROUP_TWO_STREAMS, _WG_GROUP_ONE_STREAM = "0", "all"
 # RSU_RAW_EVENTS=0: fork the side stream through torch events (system-scope release) instead of _lib.hip_fork (agent scope)
 _RAW_EVENTS = os.environ.get("RSU_RAW_EVENTS", "1") != "0"
+_WG_EVENTS = os.environ.get("RSU_WG_EVENTS", "0") == "1"   # grouped weight gradients: a torch event per queued job (rounds 2-3)
 _SPLIT_DEFAULT = "128,128"   # RSU_SPLIT_CHIP: CUs the main stream / each side stream plan for during the backward pass (UNet._Side)
 
 
@@ -464,8 +465,9 @@ class UNet:
         cin = sum(s.C for s in srcs)
         ho = hin - 2 * dil
         kws = self._kws()
-        self._timed("conv3x3_fwd", 2.0 * self.B * ho * ho * cout * cin * 9, "rsu_conv2d_fwd_k", arr, len(srcs),
-                    _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), self.B, hin, hin, cout, dil, 1,
+        nb = out.shape[0]   # (the batch of the tensors at hand: forward_device may run the two halves of a batch as two chains)
+        self._timed("conv3x3_fwd", 2.0 * nb * ho * ho * cout * cin * 9, "rsu_conv2d_fwd_k", arr, len(srcs),
+                    _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), nb, hin, hin, cout, dil, 1,
                     self._ncu, _ptr(kws), kws.numel() if kws is not None else 0, self._stream())
 
     def _kws(self):
@@ -477,9 +479,9 @@ class UNet:
             return self.kws_side
         return self.kws if all(cur != s for s in self.wstreams) else None
 
-    def _conv_first(self, name, out, h, dil, st):
-        call("rsu_conv_first_fwd", _ptr(self.in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out),
-             self.B, h, h, self.root, dil, self._ncu, st)
+    def _conv_first(self, name, out, h, dil, st, in16=None):
+        call("rsu_conv_first_fwd", _ptr(self.in16 if in16 is None else in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]),
+             _ptr(out), out.shape[0], h, h, self.root, dil, self._ncu, st)
 
     def dropout_key(self, site):
         """32-bit key of dropout site `site` (encoder level i -> i, decoder stage i -> L + i: the 2L-1 tf.nn.dropout calls of
@@ -488,68 +490,90 @@ class UNet:
 
     def forward_device(self, want_logits=False, keep=1.0):
         """unet.forward (unet.py:12-97) on self.x (already on device); keep = dropout_keep (1.0: none); fills self.prob."""
-        B, L, S, st, a = self.B, self.L, self.S, self._stream(), self.act
         keep = float(keep)
         assert 0.0 < keep <= 1.0, "dropout keep probability must be in (0, 1]"
         self.keep = keep
-        call("rsu_color_adjust_fwd", _ptr(self.x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
-             _ptr(self.in16), B * S * S, keep, self.dropout_key(0), st)
+        for f in self._forward_steps(0, self.B, want_logits, keep):
+            f()
+        return self.act[self.last_name]
+
+    def _forward_steps(self, b0, nb, want_logits, keep):
+        """the launches of a forward pass over images [b0, b0 + nb) as a list of closures (one ABI call each, issued on the stream that is
+        current when the closure runs). (Two chains over the halves of a batch on two streams were measured: -2..-4 % on the step,
+        profiles/r04/fwd_halves_probe.txt.)"""
+        L, S = self.L, self.S
+        a = {k: t[b0:b0 + nb] for k, t in self.act.items()}
+        x, in16, prob, logits = self.x[b0:b0 + nb], self.in16[b0:b0 + nb], self.prob[b0:b0 + nb], self.logits[b0:b0 + nb]
+        code = {k: t[b0:b0 + nb] for k, t in self.pool_code.items()}
+        steps = []
+
+        def add(f):
+            steps.append(f)
+        add(lambda: call("rsu_color_adjust_fwd", _ptr(x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
+                         _ptr(in16), nb * S * S, keep, self.dropout_key(0), self._stream()))
         cur, h = None, S
         for i in range(L):
             last = i == L - 1
             if self.dilated and not last:
                 # the dilated twin block (unet.py:32-39) reads the level's input and feeds only a decoder skip: it runs on the second
                 # stream beside the main block (joined in front of the decoder)
-                with UNet._Side(self):
-                    if i == 0:
-                        self._conv_first("conv_dilut_0/atrous_conv1", a["d1_0"], h, 2, self._stream())
-                    else:
-                        self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
-                    self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
+                def twin(i=i, cur=cur, h=h):
+                    with UNet._Side(self):
+                        if i == 0:
+                            self._conv_first("conv_dilut_0/atrous_conv1", a["d1_0"], h, 2, self._stream(), in16)
+                        else:
+                            self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
+                        self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
+                add(twin)
             if i == 0:
-                self._conv_first("conv_0/conv1", a["c1_0"], h, 1, st)
+                add(lambda h=h: self._conv_first("conv_0/conv1", a["c1_0"], h, 1, self._stream(), in16))
             else:
-                self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i])
+                add(lambda i=i, cur=cur, h=h: self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i]))
             if last:
-                self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i])
+                add(lambda i=i, h=h: self._conv("conv_%d/conv2" % i, [_src(a["c1_%d" % i], h - 2, h - 2)], h - 2, a["c2_%d" % i]))
             else:
                 # conv2 + ReLU + the level's 2x2 max-pool (+ the next level's dropout, + the code bytes of the gradient junction): one
                 # call, one launch where the pool folds into the conv's epilogue (rsu.h rsu_conv2d_fwd_pool)
-                c1, c2 = a["c1_%d" % i], a["c2_%d" % i]
-                nf_ = c2.shape[3]
-                src = (RsuSrc * 1)(_src(c1, h - 2, h - 2))
-                kws = self._kws()
-                self._timed("conv3x3_fwd", 2.0 * B * (h - 4) * (h - 4) * nf_ * c1.shape[3] * 9, "rsu_conv2d_fwd_pool_k", src, 1,
-                            _ptr(self.pk["conv_%d/conv2/kernel" % i, "fwd"]), _ptr(self.w["conv_%d/conv2/bias" % i]), _ptr(c2),
-                            _ptr(a["pool_%d" % i]), _ptr(self.pool_code.get(i)), B, h - 2, h - 2, nf_, keep, self.dropout_key(i + 1), self._ncu,
-                            _ptr(kws), kws.numel() if kws is not None else 0, st)
+                def conv2_pool(i=i, h=h):
+                    c1, c2 = a["c1_%d" % i], a["c2_%d" % i]
+                    nf_ = c2.shape[3]
+                    src = (RsuSrc * 1)(_src(c1, h - 2, h - 2))
+                    kws = self._kws()
+                    self._timed("conv3x3_fwd", 2.0 * nb * (h - 4) * (h - 4) * nf_ * c1.shape[3] * 9, "rsu_conv2d_fwd_pool_k", src, 1,
+                                _ptr(self.pk["conv_%d/conv2/kernel" % i, "fwd"]), _ptr(self.w["conv_%d/conv2/bias" % i]), _ptr(c2),
+                                _ptr(a["pool_%d" % i]), _ptr(code.get(i)), nb, h - 2, h - 2, nf_, keep, self.dropout_key(i + 1), self._ncu,
+                                _ptr(kws), kws.numel() if kws is not None else 0, self._stream())
+                add(conv2_pool)
                 cur, h = a["pool_%d" % i], (h - 4) // 2
         net, h = a["c2_%d" % (L - 1)], h - 4
         if self.dilated:
-            self._join_side()
+            add(self._join_side)
         for i in range(L - 1):
             j, lvl = L + i, L - 2 - i
             up = a["up_%d" % i]
             if keep < 1.0:  # unet.py:64-65
-                drop = a.get("drop_%d" % i)
-                if drop is None:
-                    drop = a["drop_%d" % i] = torch.zeros_like(net)
-                call("rsu_dropout_fwd", _ptr(net), _ptr(drop), net.numel(), keep, self.dropout_key(L + i), st)
+                if self.act.get("drop_%d" % i) is None:
+                    self.act["drop_%d" % i] = torch.zeros_like(self.act["c2_%d" % (j - 1)] if i > 0 else self.act["c2_%d" % (L - 1)])
+                drop = self.act["drop_%d" % i][b0:b0 + nb]
+                add(lambda net=net, drop=drop, i=i: call("rsu_dropout_fwd", _ptr(net), _ptr(drop), net.numel(), keep, self.dropout_key(L + i), self._stream()))
                 net = drop
-            call("rsu_convT2x2_fwd", _ptr(net), _ptr(self.pk["up_conv_%d/kernel" % i, "fwd"]), _ptr(self.w["up_conv_%d/bias" % i]), _ptr(up),
-                 B, h, h, net.shape[3], up.shape[3], self._ncu, st)
+            add(lambda net=net, up=up, i=i, h=h: call("rsu_convT2x2_fwd", _ptr(net), _ptr(self.pk["up_conv_%d/kernel" % i, "fwd"]),
+                                                     _ptr(self.w["up_conv_%d/bias" % i]), _ptr(up), nb, h, h, net.shape[3], up.shape[3], self._ncu, self._stream()))
             h = 2 * h
-            srcs = [_src(a["c2_%d" % lvl], h, h)]
-            if self.dilated:
-                srcs.append(_src(a["d2_%d" % lvl], h, h))
-            srcs.append(_src(up, h, h))
-            self._conv("conv_%d/conv1" % j, srcs, h, a["c1_%d" % j])
-            self._conv("conv_%d/conv2" % j, [_src(a["c1_%d" % j], h - 2, h - 2)], h - 2, a["c2_%d" % j])
+
+            def dec(j=j, lvl=lvl, up=up, h=h):
+                srcs = [_src(a["c2_%d" % lvl], h, h)]
+                if self.dilated:
+                    srcs.append(_src(a["d2_%d" % lvl], h, h))
+                srcs.append(_src(up, h, h))
+                self._conv("conv_%d/conv1" % j, srcs, h, a["c1_%d" % j])
+            add(dec)
+            add(lambda j=j, h=h: self._conv("conv_%d/conv2" % j, [_src(a["c1_%d" % j], h - 2, h - 2)], h - 2, a["c2_%d" % j]))
             net, h = a["c2_%d" % j], h - 4
         if not self.training or want_logits:
-            call("rsu_head_fwd", _ptr(net), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(self.prob),
-                 _ptr(self.logits) if want_logits else None, B * self.P * self.P, self.root, st)
-        return net
+            add(lambda net=net: call("rsu_head_fwd", _ptr(net), _ptr(self.w["weight_output/kernel"]), _ptr(self.w["weight_output/bias"]), _ptr(prob),
+                                     _ptr(logits) if want_logits else None, nb * self.P * self.P, self.root, self._stream()))
+        return steps
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, name, srcs_t, dz, hout, dil=1):
@@ -565,7 +589,11 @@ class UNet:
                                   db.data_ptr() if db is not None else None, hout, hout, cin_total, off, cout, dil)
                 self._wg_pending.append((job, 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, (name, off)))
                 off += t.shape[3]
-            self._wg_event = self._record_main()   # everything these jobs read has been issued by now: the group need not wait for more
+            # (rounds 2-3 recorded a torch event on the main stream here, per queued job, so that a group flushed later would not wait for
+            # more than it reads: every record costs the main queue ~5 us between two backward-data kernels -- RSU_WG_EVENTS=1 restores it.
+            # Now the group forks where it is flushed, through the raw event of _Side.)
+            if _WG_EVENTS:
+                self._wg_event = self._record_main()
             if name.endswith("conv2") and not (name.startswith("conv_0/") and not self.dilated):   # (the last group: flushed by the caller, which knows that nothing runs beside it)
                 # a group closes BEHIND a conv2 gradient: dz of a block's conv2 is there when the block's backward pass begins, so the
                 # group {conv1 (+ transposed conv) of the block before, conv2 of this one} can run beside ALL of this block's
@@ -590,7 +618,8 @@ class UNet:
             job = RsuWgradJob(_lib.WGRAD_CONVT2X2, RsuSrc(upin.data_ptr(), hh, hh, upin.shape[3], 0, 0), dup.data_ptr(),
                               self.g["up_conv_%d/kernel" % i].data_ptr(), self.g["up_conv_%d/bias" % i].data_ptr(), 0, 0, 0, 0, nf, 1)
             self._wgT_pending.append((job, 0.0, ("up_conv_%d" % i, upin.data_ptr())))
-            self._wg_event = self._record_main()
+            if _WG_EVENTS:
+                self._wg_event = self._record_main()
             return
         with UNet._Side(self) as side:
             call("rsu_convT2x2_bwd_weight", _ptr(upin), _ptr(dup), _ptr(self.g["up_conv_%d/kernel" % i]), _ptr(self.g["up_conv_%d/bias" % i]),
@@ -616,7 +645,7 @@ class UNet:
                 chunk, rest = pending[:_lib.WGRAD_GROUP_MAX], pending[_lib.WGRAD_GROUP_MAX:]
                 del pending[:]
                 pending.extend(rest)
-                with UNet._Side(self, alone=alone, after=self._wg_event) as side:
+                with UNet._Side(self, alone=alone, after=self._wg_event if _WG_EVENTS else None) as side:
                     key = (tuple(k for _, _, k in chunk), self._ncu, side.ws.data_ptr())
                     plan = self._wg_plans.get(key)
                     if plan is None:
