@@ -33,6 +33,12 @@
 
 // PP_DIL: the dilation this translation unit is built for (1: igemm_pp.hip itself; 2: igemm_pp_d2.hip, which includes this file with the
 // exported names changed -- the dilated twin blocks of unet.py:32-39). The halo tile is 2 * DIL wider and higher, taps are DIL pixels apart.
+#ifndef PP_TRS
+#define PP_TRS 1      // developer A/B switch: backward-data's epilogue stores transposed across the lanes (see TRS below)
+#endif
+#ifndef PP_TRS_LA
+#define PP_TRS_LA 8    // ... with the exchanges of this many stores in flight ahead of the store being issued
+#endif
 #ifndef PP_DIL
 #define PP_DIL 1
 #endif
@@ -351,17 +357,26 @@ igemm_pp_kernel(const IgFwdParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the ordinary loads before the LDS-DMA stream starts
 
+    // The epilogue of backward-data (the one with the ReLU mask) stores TRANSPOSED across the lanes (TRS): the MFMA leaves lane (g4, l15) with
+    // pixel l15 of a fragment and the 16 bytes g4 of that pixel's 64-byte channel group -- stored as they lie, neighbouring lanes write 16
+    // bytes each one pixel (outC * 2 bytes) apart and the address unit, which merges the 4 x 16 bytes of a lane quad into one 64-byte
+    // request, gets nothing to merge: 64 requests per store instead of 16 (probes/probe_store_shapes.hip: a tile's burst of stores costs
+    // ~3200 cycles in this shape, ~1100 with quads of 64 contiguous bytes). Four ds_bpermute_b32 per store hand lane L the words of lane
+    // (L & 3) * 16 + (L >> 2): lane L then covers pixel L >> 2, bytes 16 * (L & 3); the mask is loaded in the same layout (coalesced as
+    // well) and applied behind the exchange. Measured per layer at fixed tile shapes (tools/pp_fixed.py, profiles/r04/epilogue_variants.txt):
+    // backward-data -2 ... -8 %; the forward epilogue (no mask to wait for, its stores spread between the conversions) loses 2-4 % to the
+    // exchanges and keeps the MFMA layout, as does the pooling epilogue (its 2x2 windows pair l15 neighbours).
     // scalar byte offset of a tile's first output pixel (+ this wave's first channel) and per-lane offset of epilogue store e
     auto out_sbase = [&](const Tile& T) {
         return (unsigned)((((long)(T.n * p.oH + T.y0) * p.oW + T.x0) * p.outC + cob * TN + wco * (CT / 2) * 32) * 2);
     };
-    auto out_voff = [&](const Tile& T, int e) {
+    auto out_voff = [&](const Tile& T, int e, const int ql15, const int qg4) {   // (ql15, qg4): pixel and 16-byte group this lane stores
         const int pt = e / (CT / 2), pp = e % (CT / 2);
-        const int ml = (wpx * PT + pt) * 16 + l15;
+        const int ml = (wpx * PT + pt) * 16 + ql15;
         const int ty = ml >> lsw, tx = ml & (SW - 1);
         const bool pok = (T.y0 + ty < p.Ho) && (T.x0 + tx < p.Wo);
-        const int ovoff_pt = ((ty * p.oW + tx) * p.outC + 8 * g4) * 2;
-        const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * g4;
+        const int ovoff_pt = ((ty * p.oW + tx) * p.outC + 8 * qg4) * 2;
+        const int co = cob * TN + (wco * (CT / 2) + pp) * 32 + 8 * qg4;
         return (pok && co < p.Cout) ? (unsigned)(ovoff_pt + pp * 64) : RSU_SENT;
     };
 // store + its wait states as ONE asm statement (the >64-bit store / VALU-write hazard). The leading s_nop 4:
@@ -489,15 +504,29 @@ igemm_pp_kernel(const IgFwdParams p) {
             const short fl = p.relu ? (short)0 : (short)-32768;
             const s2 floor2 = {fl, fl};
             unsigned voffs[NST];
-            if (inside) {   // (wave-uniform)
+            auto fill_voffs = [&](const bool tr) __attribute__((always_inline)) {   // tr: the transposed lane layout (computed here, no registers of the loop)
+                const int ql15 = tr ? (lane >> 2) : l15, qg4 = tr ? (lane & 3) : g4;
+                if (inside) {   // (wave-uniform)
 #pragma unroll
-                for (int e = 0; e < NST; ++e) voffs[e] = ovoff[e / (CT / 2)] + (e % (CT / 2)) * 64;
-            } else {
+                    for (int e = 0; e < NST; ++e) {
+                        const int pt = e / (CT / 2);
+                        unsigned o = ovoff[pt];
+                        if (tr) {
+                            const int ml = (wpx * PT + pt) * 16 + ql15;
+                            o = (unsigned)((((ml >> lsw) * p.oW + (ml & (SW - 1))) * p.outC + 8 * qg4) * 2);
+                        }
+                        voffs[e] = o + (e % (CT / 2)) * 64;
+                    }
+                } else {
 #pragma unroll
-                for (int e = 0; e < NST; ++e) voffs[e] = out_voff(T, e);
-            }
-            seg_end(6);
+                    for (int e = 0; e < NST; ++e) voffs[e] = out_voff(T, e, ql15, qg4);
+                }
+            };
             auto body = [&](const bool MASK) __attribute__((always_inline)) {   // (called with a constant: two straight-line copies)
+                const bool TRS = PP_TRS && MASK;
+                const int tr_src = (((lane & 3) << 4) | (lane >> 2)) << 2;   // ds_bpermute byte index of the lane whose words this lane stores
+                fill_voffs(TRS);
+                seg_end(6);
                 unsigned ones_pk = 0x00010001u;
                 asm volatile("" : "+v"(ones_pk));
                 u32x4 mk4[NST];
@@ -508,20 +537,45 @@ igemm_pp_kernel(const IgFwdParams p) {
 #pragma unroll
                     for (int e = 0; e < NST; ++e)
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(mk4[e]) : "v"(voffs[e]), "s"(mrsrc), "s"(sbase) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int e = 0; e < NST; ++e) asm volatile("" : "+v"(mk4[e]));
                 }
-#pragma unroll
-                for (int e = 0; e < NST; ++e) {
+                // The packed results of LA stores ahead, their (TRS) lane exchanges in flight: a ds_bpermute_b32 comes back after ~150 cycles,
+                // four of them waited for in front of each store would cost the interval 8 x that. The exchanges are asm with counted
+                // waits of our own (LDS operations return in order; the "+v" of the wait statement keeps the uses behind it)
+                const int LA = TRS ? (NST < PP_TRS_LA ? NST : PP_TRS_LA) : 1;   // (without exchanges: convert, store, convert, store ... as before)
+                u32x4 rr[NST];
+                auto pack = [&](const int e) __attribute__((always_inline)) {
                     const int pt = e / (CT / 2), pp = e % (CT / 2);
-                    u32x4 r;
+                    unsigned q[4];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const unsigned lo = pack_bf2(acc[2 * pp][pt][2 * i], acc[2 * pp][pt][2 * i + 1]);
                         const unsigned hi = pack_bf2(acc[2 * pp + 1][pt][2 * i], acc[2 * pp + 1][pt][2 * i + 1]);
-                        r[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
-                        r[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                        q[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+                        q[2 + i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+                    }
+                    if (TRS) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(q[i]) : "v"(tr_src), "v"(q[i]));
+                    }
+                    rr[e] = u32x4{q[0], q[1], q[2], q[3]};
+                };
+#pragma unroll
+                for (int e = 0; e < NST; ++e) {
+                    if (e == 0) {
+#pragma unroll
+                        for (int k = 0; k < LA; ++k) pack(k);
+                        if (MASK) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(mk4[k]));
+                        }
+                    } else if (e + LA - 1 < NST) {
+                        pack(e + LA - 1);
+                    }
+                    u32x4 r = rr[e];
+                    if (TRS) {   // the exchanges of stores 0..e are back (lgkmcnt is a 4-bit counter)
+                        const int ahead = (e + LA < NST ? e + LA : NST) - e - 1;
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(4 * ahead < 15 ? 4 * ahead : 15));
                     }
                     if (MASK) {
 #pragma unroll
@@ -536,6 +590,7 @@ igemm_pp_kernel(const IgFwdParams p) {
             };
             if constexpr (POOL_OK) {
                 if (p.pool_out) {   // (wave-uniform) forward conv2 of an encoder level: y, the 2x2 max-pool of y and its code bytes
+                    fill_voffs(false);
                     pool_body(T, acc, voffs, orsrc, sbase);
                     return;
                 }
@@ -636,7 +691,10 @@ igemm_pp_kernel(const IgFwdParams p) {
             // prefetch issues of this interval: halo pieces of the next chunk first, then this wave's share of stage s+2
             if constexpr (pp_na(NAW, G, J) > 0 || J == 0) {
                 if (!(DBG && (p.dbg & 2))) {
-                    if constexpr (J == 0) a_begin();
+                    if constexpr (J == 0) {
+                        a_begin();
+                        seg_end(7);
+                    }
                     a_pieces(gconst, jc);
                 }
             }
