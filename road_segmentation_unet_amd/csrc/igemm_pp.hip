@@ -919,11 +919,14 @@ __global__ void __launch_bounds__(256) k_pp_splitk_finish(const PpFinishParams q
 template <int CFG> struct PpCfg;
 #define PP_NAS(a, b, c, d, e) ((a) | ((b) << 4) | ((c) << 8) | ((d) << 12) | ((e) << 16))
 // NAS: halo pieces per wave in the slots G0/0, G1/0, G0/1, G1/1, G0/2 (sum * 4 = igemm_fwd2's halo pieces per chunk: the same LDS budget)
-template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+// WP0: the G1 waves' R intervals are the long ones (1300-1600 cycles against G0's 750-950, tools/pp_stamps_raw.py): two of a wave's six weight
+// pieces per stage go to G0 in the 128-channel shapes (tools/pp_fixed.py: forward / backward-data -2 %; three is no better; the 64-channel
+// shapes, HBM-bound, gain nothing from one of three)
+template <> struct PpCfg<IGF2_CFG_128x256> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 4, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 2; };
 template <> struct PpCfg<IGF2_CFG_64x512> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 4, NAS = PP_NAS(0, 4, 4, 2, 2), WP0 = 0; };
-template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NAS = PP_NAS(0, 1, 2, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_128x128> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 2, NAS = PP_NAS(0, 1, 2, 1, 2), WP0 = 2; };
 template <> struct PpCfg<IGF2_CFG_64x256> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 2, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
-template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 0; };
+template <> struct PpCfg<IGF2_CFG_128x192> { static constexpr int WCO = 2, WPX = 4, CT = 4, PT = 3, NAS = PP_NAS(0, 2, 3, 1, 2), WP0 = 2; };
 template <> struct PpCfg<IGF2_CFG_64x384> { static constexpr int WCO = 1, WPX = 8, CT = 4, PT = 3, NAS = PP_NAS(0, 3, 3, 2, 2), WP0 = 0; };
 // (128x320 / 64x640, five pixel fragments per wave: measured 20-40 % slower than igemm_fwd2's -- three taps of fragments beside 80
 // accumulators leave no registers for the tile bookkeeping; not instantiated)
