@@ -368,6 +368,12 @@ def main():
         attempts += 1
         prof_timed = instrumented("timed schedule")
         plausible = prof_timed["chip_s"] / nprof <= 1.15 * dt / args.steps
+        if world > 1:
+            # every rank repeats the pass or none does: its steps hold collectives (round 4: decided per rank, one rank ran a pass more than
+            # its peer and the run ended in "connection reset by peer" -- two of eight two-rank runs on a shared GPU)
+            ok = torch.tensor([1 if plausible else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            plausible = bool(ok.item())
         if plausible or attempts >= 3:
             break
     # (2), (3) serialised single-stream passes, every launch alone on the chip: one weight-gradient launch per layer (rounds 1-2's

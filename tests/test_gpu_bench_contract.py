@@ -44,7 +44,7 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--no_cpu_baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == 0, "\n".join(ln for ln in out.stderr.splitlines() if "amdgpu.ids" not in ln and "site-packages" not in ln)[-8000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
@@ -60,15 +60,11 @@ def test_bench_bare_gpus_2_starts_its_own_ranks():
     child torch.distributed.run (gloo here: the test box has one GPU) and relays rank 0's contract line"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(RSU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    errs = []
-    for attempt in range(2):   # (round 4: twice in ~10 runs rank 0 of the child launch exited with code 1 inside the first seconds, with nothing
-        # of its own on stderr, and the next run on the same box passed: one retry, both logs in the message if it fails again)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no_cpu_baseline",
-                              "--sustain_seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-        if out.returncode == 0:
-            break
-        errs.append("\n".join(ln for ln in out.stderr.splitlines() if "amdgpu.ids" not in ln)[-6000:])
-    assert out.returncode == 0, "\n======== next attempt ========\n".join(errs)
+    # (round 4: two-rank runs failed once in ~4 with "connection reset by peer" -- the repetition of an implausible instrumented pass was
+    # decided per rank, so one rank ran a pass, collectives included, more than its peer; the decision is an all-reduce now)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no_cpu_baseline",
+                          "--sustain_seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, "\n".join(ln for ln in out.stderr.splitlines() if "amdgpu.ids" not in ln and "site-packages" not in ln)[-8000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
