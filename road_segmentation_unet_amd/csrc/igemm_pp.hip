@@ -36,6 +36,9 @@
 #ifndef PP_TRS
 #define PP_TRS 1      // developer A/B switch: backward-data's epilogue stores transposed across the lanes (see TRS below)
 #endif
+#ifndef PP_CLIP_PAD
+#define PP_CLIP_PAD 1   // developer A/B switch: the padding pixels of a halo block are not fetched (setup_a)
+#endif
 #ifndef PP_TRS_LA
 #define PP_TRS_LA 8    // ... with the exchanges of this many stores in flight ahead of the store being issued
 #endif
@@ -263,8 +266,12 @@ igemm_pp_kernel(const IgFwdParams p) {
         for (int q = 0; q < NAV; ++q) {
             const int hp = my_piece(q) * 16 + lq;
             const int kg8 = ((lane & 3) ^ ((hp >> 1) & 2)) * 8;
-            const int rr = hp / CW;   // compile-time divisor
-            const int cc = hp - rr * CW;
+            const int rr0 = hp / CW;   // compile-time divisor
+            const int cc = hp - rr0 * CW;
+            // (PP_CLIP_PAD: the columns that pad a halo row to CW pixels and the rows that pad the block to NPIX are never read by a
+            // fragment -- boff stays below column SW + 2*DIL -- so their lanes ask for nothing: 15 % (strips of 32) to 28 % (strips of
+            // 16) fewer requests in the halo stream. A per-lane constant folded into the row: the range test below rejects it.)
+            const int rr = (!PP_CLIP_PAD || (cc < SW + 2 * DIL && rr0 < TR + 2 * DIL)) ? rr0 : 0x20000000;
             const bool ok = ((unsigned)(iy0 + rr) < (unsigned)p.Hin) && ((unsigned)(ix0 + cc) < (unsigned)p.Win) &&
                             (q < (grp ? pp_na_total(NAW, 1) : pp_na_total(NAW, 0)));
             a_voff[q] = ok ? (unsigned)(((rr * sW + cc) * sC + kg8) * 2) : RSU_SENT;
