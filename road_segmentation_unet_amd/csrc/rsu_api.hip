@@ -450,7 +450,6 @@ static int pick_cob_group(int grid, int ncob, int ksplit, int TN, int ktot, int 
 }
 static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, int ntap, int kh, int kw, int dil, int stride, int gy, int ktot,
                       int force_cfg, bool shared_chip = false, bool pool = false) {
-    const int force_lsw = env_int("RSU_FWD2_LSW", 0);   // (0: the cost model picks the strip width; tools/r04_lsw_sweep.sh)
     double best_cost = 1e300;
     bool have = false;
     // pass 0: channel-block width matched to Cout; pass 1 (only when no such shape fits its halo tile into LDS -- the 2x2 stride-2
@@ -463,10 +462,8 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
         const IgFwdCfgInfo ci = igemm_fwd2_cfg_info(cfg);
         if (pass == 0 && Cout <= 64 && ci.TN > 64 && force_cfg < 0) continue;
         if (pass == 0 && Cout > 64 && ci.TN <= 64 && force_cfg < 0) continue;
-        int lsw_mask = pool ? igemm_pp_pool_lsw_mask(cfg) : 0;
+        const int lsw_mask = pool ? igemm_pp_pool_lsw_mask(cfg) : 0;
         if (pool && !lsw_mask) continue;
-        if (force_lsw > 0) lsw_mask = lsw_mask ? (lsw_mask & (1 << force_lsw)) : (1 << force_lsw);   // (developer switch RSU_FWD2_LSW: this strip width only)
-        if (force_lsw > 0 && !lsw_mask) continue;
         const long fixed = (long)igemm_fwd2_lds_bytes(cfg, ntap, 0);
         const long per_pix = (long)igemm_fwd2_lds_bytes(cfg, ntap, 1) - fixed;  // 64 bytes x halo ring slots
         int cap = (int)((160 * 1024 - fixed) / per_pix);
