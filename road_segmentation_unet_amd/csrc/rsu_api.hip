@@ -533,13 +533,16 @@ static bool plan_split(Fwd2Plan& pl, int N, int Ho, int Wo, int Cout, int ktot, 
         int lsw = 0;
         if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, 3, 3, dil, 1, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
+        // (RSU_KSPLIT_PERIMG=1, probe: the slice count from the pairs of ONE image, so that an image's arithmetic does not depend on its batch)
+        const bool perimg = env_int("RSU_KSPLIT_PERIMG", 0) != 0;
+        const long Pd = (long)(perimg ? 1 : N) * g.nstrips * g.tiles_per_strip * ncob;   // pairs the slice count is decided from
         const long P = (long)N * g.nstrips * g.tiles_per_strip * ncob;
-        if (P > 128) continue;
-        int S = (int)(256 / P);
+        if (Pd > 128) continue;
+        int S = (int)(256 / Pd);
         if (S > nchunks / 4) S = nchunks / 4;
         if (S > 16) S = 16;
         if (S < 2) continue;
-        if (k == 0 && P * S < 192 && nchunks / 4 > S) continue;   // (the smaller tiles fill the chip better: see whether they split too)
+        if (k == 0 && Pd * S < 192 && nchunks / 4 > S) continue;   // (the smaller tiles fill the chip better: see whether they split too)
         if ((size_t)S * (size_t)P * ci.TM * ci.TN > kws_floats) continue;
         {   // ... and the ping-pong kernel must be instantiated for this geometry
             IgFwdParams t;

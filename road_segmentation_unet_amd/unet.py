@@ -238,8 +238,11 @@ class UNet:
         # workspace of the conv launches that cut their reduction into slices (rsu.h rsu_conv2d_fwd_k: the deep levels at small batches);
         # one per stream that issues conv launches -- the main stream, and the side stream of the dilated twin blocks in the forward pass
         nk = int(_lib.lib().rsu_conv_splitk_ws_floats()) if os.environ.get("RSU_KSPLIT", "1") != "0" else 0
+        if os.environ.get("RSU_KSPLIT_PERIMG", "0") != "0":   # (probe: per-image slice counts need a batch's worth of slices)
+            nk *= B
         self.kws = torch.zeros(nk, dtype=torch.float32, device=dev) if nk else None
-        self.kws_side = torch.zeros(nk, dtype=torch.float32, device=dev) if (nk and self.dilated and self.wstreams) else None
+        # (one per side stream: whether a layer splits must never depend on which stream its launch went to)
+        self.kws_side = [torch.zeros(nk, dtype=torch.float32, device=dev) for _ in self.wstreams] if (nk and self.dilated) else []
         if self.training:
             for k, t in self.act.items():
                 if k.startswith("up_") or k.startswith("c") or k.startswith("d") or k.startswith("pool_"):
@@ -475,9 +478,10 @@ class UNet:
         if self.kws is None or not self.wstreams:
             return self.kws
         cur = torch.cuda.current_stream(self.device)
-        if cur == self.wstreams[0]:
-            return self.kws_side
-        return self.kws if all(cur != s for s in self.wstreams) else None
+        for k, s in enumerate(self.wstreams):
+            if cur == s:
+                return self.kws_side[k] if k < len(self.kws_side) else None
+        return self.kws
 
     def _conv_first(self, name, out, h, dil, st, in16=None):
         call("rsu_conv_first_fwd", _ptr(self.in16 if in16 is None else in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]),

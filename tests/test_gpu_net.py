@@ -293,7 +293,7 @@ def test_c2_benchmarked_batch_of_four_equals_one_patch(wgrad_stream, monkeypatch
     record("c2_batch4_vs_batch1_wgrad_stream_" + wgrad_stream, loss_b4=l4, loss_b1=l1, worst_grad_rel_err=worst[1], worst_grad_tensor=worst[0])
 
 
-def test_c2_full_size_gradients_match_oracle():
+def test_c2_full_size_gradients_match_oracle(monkeypatch):
     """config 2 geometry, one patch: loss and EVERY gradient tensor against the bf16-emulating oracle (Frobenius), tolerance =
     max(2e-2, the oracles' own bf16-vs-f32 distance) as in the small cases. ~30 s of oracle time on the host cores: this is the
     test that exercises the large tile shapes and multi-tile workgroups of all three MFMA kernels end to end."""
@@ -313,3 +313,32 @@ def test_c2_full_size_gradients_match_oracle():
     for n, e in errs.items():
         assert e <= C2_GRAD_REL_MAX, (n, e)
     assert float(np.abs(prob - emu[1]).max()) <= C2_FWD_EMU_MAX
+    # ---- the BENCHMARKED configuration against the same oracle run: four copies of the patch have the one-patch loss, probabilities and
+    # gradients in the oracle too (mean over the batch), so the B = 4 step -- behind the explicit tuning pass bench.py runs, in both
+    # schedules of the backward pass, with the tile shapes, pixel splits and reduction splits of N = 4 -- is checked at the oracle's
+    # tolerances, not against the HIP path itself
+    X4, lab4 = np.concatenate([X] * 4), np.concatenate([labels] * 4)
+    for wgrad_stream in ("1", "0"):
+        monkeypatch.setenv("RSU_WGRAD_STREAM", wgrad_stream)
+        m4 = UNet(L, root, False, 4, P, params=params, training=True)
+        assert bool(m4.wstreams) == (wgrad_stream == "1")
+        m4.tune()
+        m4.x.copy_(torch.from_numpy(X4))
+        m4.labels.copy_(torch.from_numpy(lab4))
+        m4.forward_device()
+        m4.backward_device(1.0 / (4 * P * P))
+        torch.cuda.synchronize()
+        loss4 = float(m4.loss_sum.item()) / (4 * P * P)
+        prob4 = m4.prob.cpu().numpy()
+        g4 = {n: m4.g[n].detach().cpu().numpy().copy() for n in m4.names}
+        del m4
+        assert abs(loss4 - emu[0]) <= 2e-4 * abs(emu[0]), (wgrad_stream, loss4, emu[0])
+        d4 = max(float(np.abs(prob4[b] - emu[1][0]).max()) for b in range(4))
+        assert d4 <= C2_FWD_EMU_MAX, (wgrad_stream, d4)
+        errs4 = _rel_errs(g4, emu[2])
+        w4 = max(errs4, key=errs4.get)
+        record("c2_batch4_vs_oracle_wgrad_stream_" + wgrad_stream, loss_hip=loss4, loss_emu=emu[0], prob_d_emu_max=d4,
+               worst_grad_rel_err=errs4[w4], worst_grad_tensor=w4)
+        print("c2 B=4 (wgrad stream %s) vs oracle: worst gradient rel err %s %.2e, prob %.2e" % (wgrad_stream, w4, errs4[w4], d4))
+        for n, e in errs4.items():
+            assert e <= C2_GRAD_REL_MAX, (wgrad_stream, n, e)
