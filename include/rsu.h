@@ -176,8 +176,12 @@ int rsu_conv2d_fwd(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, cons
  * reduction (taps x input channels) into up to 16 slices, one workgroup per (tile, block, slice): the slices' fp32 partial sums go to
  * `kws` and a second launch sums them IN SLICE ORDER (deterministic), adds nothing else (the bias rides in slice 0), applies ReLU /
  * the ReLU mask and stores bf16. Results equal the unsplit launch up to the association of the fp32 sum over the slices. Whether a launch
- * splits is decided by the planner's cost model and, behind a tuning pass, by measurement (RSU_KSPLIT=0: never). The workspace must not
- * be shared with a launch running concurrently on another stream. */
+ * splits, and into how many slices, is a pure function of its geometry (N, output size, channel counts, dilation) -- never of the CU
+ * budget, the tuning table or a measurement: the same launch sums in the same order in every schedule and on every box (RSU_KSPLIT=0:
+ * never split). The geometry includes the batch: a layer splits into more slices at N = 1 than at N = 4, so the deep layers of one image
+ * associate their fp32 sums differently in batches of different size (the distance is pinned per layer in tests/test_gpu_ops.py; making
+ * the rule batch-independent cost the N = 4 step 12-14 %, profiles/r05/abenv_perimg_*.txt). The workspace must not be shared with a launch
+ * running concurrently on another stream: the host keeps one per stream that issues conv launches. */
 size_t rsu_conv_splitk_ws_floats(void);
 int rsu_conv2d_fwd_k(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, int N,
                      int Hin, int Win, int Cout, int dil, int relu, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
@@ -187,9 +191,10 @@ int rsu_conv2d_bwd_data_k(const void* dz, const void* packed_bwd, void* dx, cons
                           int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
 /* unet.py:44-52 in one launch: y = relu(conv3x3_valid(concat(srcs), W) + b) (dilation 1), pooled = max_pooling2d(y, 2, 2) followed by
  * the next level's dropout (keep, key as rsu_maxpool2x2_fwd), and -- code != NULL -- the code bytes of rsu_maxpool2x2_fwd_code.
- * The conv's output size must be even. Where a tile shape with whole 2x2 windows per wavefront fits the layer and keep == 1 the
- * pool is part of the conv kernel's epilogue (lane shuffles on the packed results; the activation is not read back from HBM);
- * otherwise the call issues the two launches itself. Same bits either way. */
+ * With code != NULL the conv's output size must be even (RSU_EINVAL before anything is launched otherwise); without code bytes odd
+ * sizes pool with floor semantics, as max_pooling2d does. Where a tile shape with whole 2x2 windows per wavefront fits the layer, the
+ * size is even and keep == 1 the pool is part of the conv kernel's epilogue (lane shuffles on the packed results; the activation is not
+ * read back from HBM); otherwise the call issues the two launches itself. Same bits either way. */
 int rsu_conv2d_fwd_pool(const rsu_src_t* srcs, int nsrc, const void* packed_fwd, const float* bias, void* y, void* pooled, void* code,
                         int N, int Hin, int Win, int Cout, float keep, unsigned key, int ncu, rsu_stream_t stream);
 /* Conv2DBackpropInput for input channels [ci_off, ci_off+ci_cnt) of a conv with Cin_total inputs:

@@ -42,6 +42,9 @@
 #ifndef PP_TRS_LA
 #define PP_TRS_LA 8    // ... with the exchanges of this many stores in flight ahead of the store being issued
 #endif
+#ifndef PP_TRS_FWD
+#define PP_TRS_FWD 0   // developer A/B switch: the transposed stores in the epilogue without a mask too (forward; measured slower in round 4)
+#endif
 #ifndef PP_DIL
 #define PP_DIL 1
 #endif
@@ -530,7 +533,7 @@ igemm_pp_kernel(const IgFwdParams p) {
                 }
             };
             auto body = [&](const bool MASK) __attribute__((always_inline)) {   // (called with a constant: two straight-line copies)
-                const bool TRS = PP_TRS && MASK;
+                const bool TRS = PP_TRS && (MASK || PP_TRS_FWD);
                 const int tr_src = (((lane & 3) << 4) | (lane >> 2)) << 2;   // ds_bpermute byte index of the lane whose words this lane stores
                 fill_voffs(TRS);
                 seg_end(6);

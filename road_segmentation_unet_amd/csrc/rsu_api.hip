@@ -513,7 +513,12 @@ static bool plan_fwd2(Fwd2Plan& best, int ncu, int N, int Ho, int Wo, int Cout, 
 static bool pp_supports(int cfg, const IgFwdParams& p) { return p.dil == 2 ? igemm_pp_d2_supports(cfg, p) : igemm_pp_supports(cfg, p); }
 // Split-K plan of a 3x3 stride-1 launch, or false. A PURE FUNCTION OF THE LAYER'S GEOMETRY (never of the CU budget, the tuning table or
 // a measurement), so that the same layer sums its reduction in the same order in every schedule, on every box: results stay repeatable bit
-// for bit across one / two streams and tuned / untuned runs. Rule: with P = (pixel tiles) x (128-channel blocks) of the 128x256 shape, or
+// for bit across one / two streams and tuned / untuned runs. The geometry INCLUDES THE BATCH: P counts the tiles of all N images, so the same
+// layer is cut into more slices at N = 1 than at N = 4, and an image's deep-layer sums associate differently with its batch size (and between
+// the shared-window and the tile-by-tile inference paths). Deciding the slice count from ONE image's tiles was measured (round 5,
+// profiles/r05/abenv_perimg_c2.txt / _c4.txt): 8 slices of every N = 4 launch cost the c2 step 14 % and the c4 step 12 % (four times the
+// fp32 partial sums), so the batch stays in the rule; tests/test_gpu_ops.py pins the |N = 1 - N = 4| distance per layer instead.
+// Rule: with P = (pixel tiles) x (128-channel blocks) of the 128x256 shape, or
 // failing that of the 128x128 shape, a layer with P <= 128 cuts its reduction into S = min(256 / P, chunks / 4, 16) >= 2 slices of at least
 // four 32-channel chunks; the launch then has P x S workgroups of ONE tile slice each (the hardware deals them over the CUs; a launch
 // planned for half the chip simply takes two turns), followed by the finish launch. Needs S x P x (tile floats) of workspace.
@@ -533,16 +538,13 @@ static bool plan_split(Fwd2Plan& pl, int N, int Ho, int Wo, int Cout, int ktot, 
         int lsw = 0;
         if (!plan_geo_aligned(g, lsw, Ho, Wo, ci.TM, 3, 3, dil, 1, cap)) continue;
         const int ncob = cdiv(Cout, ci.TN);
-        // (RSU_KSPLIT_PERIMG=1, probe: the slice count from the pairs of ONE image, so that an image's arithmetic does not depend on its batch)
-        const bool perimg = env_int("RSU_KSPLIT_PERIMG", 0) != 0;
-        const long Pd = (long)(perimg ? 1 : N) * g.nstrips * g.tiles_per_strip * ncob;   // pairs the slice count is decided from
         const long P = (long)N * g.nstrips * g.tiles_per_strip * ncob;
-        if (Pd > 128) continue;
-        int S = (int)(256 / Pd);
+        if (P > 128) continue;
+        int S = (int)(256 / P);
         if (S > nchunks / 4) S = nchunks / 4;
         if (S > 16) S = 16;
         if (S < 2) continue;
-        if (k == 0 && Pd * S < 192 && nchunks / 4 > S) continue;   // (the smaller tiles fill the chip better: see whether they split too)
+        if (k == 0 && P * S < 192 && nchunks / 4 > S) continue;   // (the smaller tiles fill the chip better: see whether they split too)
         if ((size_t)S * (size_t)P * ci.TM * ci.TN > kws_floats) continue;
         {   // ... and the ping-pong kernel must be instantiated for this geometry
             IgFwdParams t;
@@ -598,7 +600,6 @@ static int run_fwd(const rsu_src_t* srcs, int nsrc, const void* wp, long wp_y_st
     // measured tile-shape choice (see g_tuned): look the launch up, or -- first time -- mark it for tuning below
     const int tune_mode = env_int("RSU_AUTOTUNE", 1) != 0 ? g_autotune.load() : RSU_TUNE_OFF;
     const bool tunable = env_cfg < 0 && !accumulate && tune_mode != RSU_TUNE_OFF;
-    (void)0;
     std::array<int, 16> tkey = {N, Ho, Wo, Cout, outC, ntap, kw, dil, stride, pad, gy, ktot, nsrc,
                                 (mask_src ? 1 : 0) | (relu ? 2 : 0) | (bias ? 4 : 0) | (pool ? 8 : 0) | (pool_code ? 16 : 0), ostride, ncu * 8 + gen};
     int tuned_cfg = -1, tuned_pp = -1;  // the tuned entry holds shape + 256 * (ping-pong kernel)
@@ -780,6 +781,7 @@ extern "C" int rsu_conv2d_fwd_pool_k(const rsu_src_t* srcs, int nsrc, const void
     if (!srcs || nsrc < 1 || nsrc > 3 || !packed_fwd || !y || !pooled || Cout % 8 || !keep_ok(keep)) return RSU_EINVAL;
     const int Ho = Hin - 2, Wo = Win - 2;
     if (Ho < 2 || Wo < 2) return RSU_EINVAL;
+    if (code && ((Ho | Wo) & 1)) return RSU_EINVAL;   // (the code bytes describe whole 2x2 windows: refused before anything is launched)
     const bool even = ((Ho | Wo) & 1) == 0;   // the folded epilogue pools whole 2x2 windows; odd sizes take the two launches (floor semantics, no code bytes)
     // the pool folds into the conv's epilogue where a ping-pong tile shape with whole window rows per wave fits the layer and no dropout
     // follows (its mask is a function of the pooled element index: the separate kernel applies it); otherwise: the two launches

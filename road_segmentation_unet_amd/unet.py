@@ -238,8 +238,6 @@ class UNet:
         # workspace of the conv launches that cut their reduction into slices (rsu.h rsu_conv2d_fwd_k: the deep levels at small batches);
         # one per stream that issues conv launches -- the main stream, and the side stream of the dilated twin blocks in the forward pass
         nk = int(_lib.lib().rsu_conv_splitk_ws_floats()) if os.environ.get("RSU_KSPLIT", "1") != "0" else 0
-        if os.environ.get("RSU_KSPLIT_PERIMG", "0") != "0":   # (probe: per-image slice counts need a batch's worth of slices)
-            nk *= B
         self.kws = torch.zeros(nk, dtype=torch.float32, device=dev) if nk else None
         # (one per side stream: whether a layer splits must never depend on which stream its launch went to)
         self.kws_side = [torch.zeros(nk, dtype=torch.float32, device=dev) for _ in self.wstreams] if (nk and self.dilated) else []

@@ -64,3 +64,14 @@ def test_rule_asm_vmem_reads_valu_written_sgpr(tmp_path, capsys):
     assert _count(tmp_path, "\tv_readlane_b32 s80, v228, 39\n" + st) == 0
     # the compiler covers its own (non-asm) VMEM instructions
     assert _count(tmp_path, "\tv_readlane_b32 s91, v228, 39\n\tbuffer_store_dwordx2 v[32:33], v139, s[88:91], s21 offen\n") == 0
+
+
+def test_rule_exchange_result_read_before_its_wait(tmp_path, capsys):
+    bp = "\t;;#ASMSTART\n\tds_bpermute_b32 v10, v193, v10\n\t;;#ASMEND\n"
+    bp2 = "\t;;#ASMSTART\n\tds_bpermute_b32 v11, v193, v11\n\t;;#ASMEND\n"
+    wait = lambda n: "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(%d)\n\t;;#ASMEND\n" % n
+    assert _count(tmp_path, bp + "\tv_mov_b32_e32 v20, v10\n" + wait(0)) == 1          # a copy scheduled in front of the wait
+    assert _count(tmp_path, bp + wait(0) + "\tv_mov_b32_e32 v20, v10\n") == 0
+    assert _count(tmp_path, bp + bp2 + wait(1) + "\tv_and_b32_e32 v20, v10, v9\n") == 0  # counted wait: one exchange may stay out
+    assert _count(tmp_path, bp + bp2 + wait(1) + "\tv_and_b32_e32 v20, v11, v9\n") == 1  # ... but not the one that is read
+    assert _count(tmp_path, bp + "\tv_mov_b32_e32 v20, v12\n" + wait(0)) == 0

@@ -13,6 +13,10 @@ and reports
       igemm_fwd2, once per ~1e4 launches), so every wide store is checked here whatever its addressing.
   (4) any inline-asm VMEM instruction that reads an SGPR a VALU instruction (v_readlane, v_readfirstlane, v_cmp ...) wrote fewer
       than SGPR_WS wait states earlier -- e.g. a spilled descriptor word restored right in front of an asm store.
+  (5) any instruction that touches the destination register of an inline-asm ds_bpermute_b32 before an s_waitcnt lgkmcnt(n) has retired it
+      (LDS operations return in order: the exchange is back once at most as many LDS / scalar-memory operations as were issued behind it
+      may still be outstanding). hipcc does not count LDS operations issued from asm, so a copy it schedules between the exchange and our
+      counted wait would read a register whose LDS return is still pending (the transposed epilogue of igemm_pp).
 A wait state is one issued instruction of the same wave (s_nop N counts N+1); instructions of other waves do not count, so the
 check is conservative. usage: check_mfma_hazards.py file.s [...]; exit status 1 when anything is reported."""
 import re
@@ -148,11 +152,49 @@ def walk(ins, labels, start, budget, visit):
             stack.append((s, el + ins[j].ws()))
 
 
+LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+BPERM_BUDGET = 600   # instructions followed behind an exchange before giving up (an epilogue holds ~300)
+
+
+def check_bpermute(path, name, ins, labels, i):
+    """rule (5) for the asm ds_bpermute_b32 at index i; returns the number of violations"""
+    dst = regs_of(ins[i].ops[0])
+    bad = 0
+    seen = {}
+    stack = [(s, 0, 0) for s in successors(ins, labels, i)]   # (index, LDS / SMEM operations issued behind the exchange, steps)
+    while stack:
+        j, later, steps = stack.pop()
+        if steps > BPERM_BUDGET or seen.get(j, -1) >= later:
+            continue
+        seen[j] = later
+        J = ins[j]
+        if J.op == "s_waitcnt":
+            m = LGKM.search(J.text)
+            if m is not None and int(m.group(1)) <= later:
+                continue   # retired on this path
+        elif J.op.startswith(("ds_", "s_load", "s_buffer_load")):
+            if J.all & dst:
+                print("%s:%d %s: '%s' touches the result of the exchange in line %d before its wait" % (path, J.line, name[:60], J.text, ins[i].line))
+                bad += 1
+                continue
+            later += 1
+        elif J.all & dst:
+            print("%s:%d %s: '%s' touches the result of the exchange in line %d before its wait" % (path, J.line, name[:60], J.text, ins[i].line))
+            bad += 1
+            continue
+        for s2 in successors(ins, labels, j):
+            stack.append((s2, later, steps + 1))
+    return bad
+
+
 def check(path):
     bad = 0
     for name, ins, labels in kernels(path):
         n_mfma = n_store = 0
         for i, I in enumerate(ins):
+            if I.asm and I.op == "ds_bpermute_b32":
+                bad += check_bpermute(path, name, ins, labels, i)
+                continue
             if I.is_mfma() and not I.asm:
                 continue  # a builtin MFMA: the compiler's own hazard recogniser covers it
             if I.is_mfma():

@@ -28,7 +28,8 @@ def run():
     if op == "fwd": call("rsu_conv2d_fwd", arr, 1, ptr(pf), ptr(bias), ptr(y), B, H, H, cout, 1, 1, 0, st)
     else: call("rsu_conv2d_bwd_data", ptr(dz), ptr(pb), ptr(dx), ptr(x), 0, B, H, H, cin, 0, cin, cout, 1, 0, st)
 for _ in range(3): run()
-os.environ["RSU_FWD_DBG"] = "128"; os.environ["RSU_STAMP_PTR"] = hex(stamps.data_ptr())
+# (RSU_STAMP_DBG: timing-ablation bits on top of the stamps, 128x256 shape only)
+os.environ["RSU_FWD_DBG"] = str(128 | int(os.environ.get("RSU_STAMP_DBG", "0"))); os.environ["RSU_STAMP_PTR"] = hex(stamps.data_ptr())
 for _ in range(3): run()
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64).reshape(256, 8, NST) & 0xFFFFFFFF
