@@ -23,7 +23,9 @@ Besides the contract line the JSON carries
                  MFMA (/opt/skills/guides/MI355X_MICROARCH.md). Two serialised single-stream passes (every kernel alone on
                  the chip) follow for comparison: `frac_serial_per_layer` (one weight-gradient launch per layer, rounds 1-2's
                  definition) and `frac_single_stream_grouped` (the single-stream product schedule with grouped weight
-                 gradients, round 3's headline). `traffic` comes from a committed PMC run and is null unless that file was
+                 gradients, round 3's headline). `frac` is an upper bound of the kernels' efficiency (a launch is billed the CUs
+                 it plans for); `frac_busy_union` is the lower bound (the whole chip billed whenever any 3x3-conv launch runs),
+                 `whole_step_frac` the figure over the whole timed step. `traffic` comes from a committed PMC run and is null unless that file was
                  measured with this very build of librsu_hip.so (sha-256 match).
   cpu_baseline : the CPU oracle (oracle/unet_oracle.c, kind "port"; TensorFlow 1.4 cannot be installed) timed on the
                  host cores on a bounded sample of the same network, rank 0 / N=1 only.
@@ -344,6 +346,8 @@ def main():
             run_step(m, bucketer, lr, mu)
         torch.cuda.synchronize()
         agg = {}
+        spans = []
+        ref = m.prof[0][2] if m.prof else None
         for tag, fl, e0, e1, share in m.prof:
             a = agg.setdefault(tag, [0.0, 0.0, 0, 0.0])
             dur = e0.elapsed_time(e1) * 1e-3
@@ -351,13 +355,30 @@ def main():
             a[1] += dur * share      # chip time: a launch planned for half of the CUs runs beside another one
             a[2] += 1
             a[3] += dur
+            t0_ = ref.elapsed_time(e0) * 1e-3
+            spans.append((t0_, t0_ + dur))
         m.prof = None
+        # union of the launches' busy intervals over both streams: the time during which AT LEAST ONE 3x3-conv launch held (part of) the
+        # chip. FLOPs over it bills the whole chip for every such moment -- a LOWER bound of the kernels' efficiency, where `achieved`
+        # (duration x planned CU share) is an upper bound whenever the two backward streams do not overlap perfectly
+        spans.sort()
+        union, cur0, cur1 = 0.0, None, None
+        for a0, a1 in spans:
+            if cur1 is None or a0 > cur1:
+                if cur1 is not None:
+                    union += cur1 - cur0
+                cur0, cur1 = a0, a1
+            else:
+                cur1 = max(cur1, a1)
+        if cur1 is not None:
+            union += cur1 - cur0
         fl = sum(a[0] for a in agg.values())
         t = sum(a[1] for a in agg.values())
         n = sum(a[2] for a in agg.values())
         by = {k: {"tflops": v[0] / v[1] / 1e12, "chip_ms_per_step": v[1] / nprof * 1e3, "wall_ms_per_step": v[3] / nprof * 1e3,
                   "launches": v[2] // nprof} for k, v in agg.items()}
-        return {"achieved": fl / t / 1e12 if t > 0 else 0.0, "by_kernel": by, "launches": n, "chip_s": t, "flops": fl, "label": label}
+        return {"achieved": fl / t / 1e12 if t > 0 else 0.0, "by_kernel": by, "launches": n, "chip_s": t, "flops": fl, "label": label,
+                "busy_union_s": union}
 
     # (1) the timed schedule itself: two streams in the backward pass, every launch with the CU share it has there. The conv launches of a
     # step cannot hold the chip for longer than the step lasts: a pass whose chip time exceeds the timed step by more than 15 % is not a
@@ -457,6 +478,12 @@ def main():
                      "launches_per_step": n_launch // nprof,
                      "avg_launch_us": sum(v["wall_ms_per_step"] for v in prof_timed["by_kernel"].values()) / max(1, n_launch // nprof) * 1e3,
                      "conv_chip_ms_per_step": conv_t / nprof * 1e3,
+                     # `frac` prices a launch by the CUs it PLANS for, so it can only overstate when the two backward streams do not overlap
+                     # perfectly (a half-chip launch beside an idle queue, an unconfined split-K launch): it is an UPPER bound of the
+                     # kernels' efficiency. The lower bound bills the whole chip whenever at least one 3x3-conv launch is running (union
+                     # of the launches' busy intervals over both streams); `whole_step_frac` bills it for the whole step.
+                     "frac_busy_union": conv_fl / prof_timed["busy_union_s"] / 1e12 / MFMA_BF16_PEAK_TFLOPS if prof_timed["busy_union_s"] > 0 else None,
+                     "conv_busy_union_ms_per_step": prof_timed["busy_union_s"] / nprof * 1e3,
                      "algorithmic_gflop_per_step": conv_fl / nprof / 1e9,
                      "by_kernel": prof_timed["by_kernel"],
                      # every launch alone on the chip, one stream (no CU shares: chip time == wall time)

@@ -136,6 +136,41 @@ def test_conv2d_fwd_split_k(N, H, W, segs, Cout, capfd, monkeypatch):
     assert (outs[0] != hu.host(y1)).mean() < 0.05
 
 
+@pytest.mark.parametrize("H,Cin,Cout", [(32, 512, 1024), (30, 1024, 1024), (20, 1024, 2048)])
+def test_split_k_plan_depends_on_the_batch_and_by_how_much(H, Cin, Cout, capfd, monkeypatch):
+    """The slice count of a split launch is a function of the geometry INCLUDING the batch (rsu.h, rsu_conv2d_fwd_k): the deep layers of c2 /
+    c4 (level 4 at 32 / 30 pixels, level 5 at 20) cut their reduction into more slices at N = 1 than at N = 4. Pinned here, per layer: four
+    copies of one image give, image by image, the N = 1 result up to the association of one fp32 sum -- at most 1 bf16 ulp on a small
+    fraction of the elements -- and both stay inside the op tolerance against the oracle. (The per-image rule that would make them equal bit
+    for bit cost the N = 4 step 12-14 %: profiles/r05/abenv_perimg_c2.txt.)"""
+    monkeypatch.setenv("RSU_PLAN_DEBUG", "1")
+    rng = np.random.RandomState(H + Cin + Cout)
+    x1 = hu.q(_rand(rng, 1, H, H, Cin))
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    wp, bd = hu.pack_conv_fwd(w), hu.dev_f32(b)
+    nk = int(lib().rsu_conv_splitk_ws_floats())
+    kws = torch.full((nk,), float("nan"), dtype=torch.float32, device=hu.DEV)
+    outs, splits = {}, {}
+    for N in (1, 4):
+        xd = hu.dev_bf16(np.concatenate([x1] * N))
+        y = torch.full((N, H - 2, H - 2, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+        srcs = (RsuSrc * 1)(hu.src_of(xd, H, H))
+        capfd.readouterr()
+        call("rsu_conv2d_fwd_k", srcs, 1, hu.ptr(wp), hu.ptr(bd), hu.ptr(y), N, H, H, Cout, 1, 1, 0, hu.ptr(kws), nk, hu.stream())
+        line = _plan_lines(capfd)[-1]
+        splits[N] = int(line.split(" ksplit")[1].split()[0])
+        outs[N] = hu.host(y)
+    assert splits[1] > splits[4] >= 1, splits   # (if the rule ever becomes batch-independent this test should turn into a bit-equality test)
+    ref = U.conv2d_fwd(x1, hu.q(w), b, relu=True)
+    hu.assert_bf16_close(outs[1], ref, "N = 1")
+    for n in range(4):
+        np.testing.assert_array_equal(outs[4][n], outs[4][0])
+    hu.assert_bf16_close(outs[4][:1], ref, "N = 4")
+    hu.assert_bf16_close(outs[4][:1], outs[1].astype(np.float64), "N = 4 vs N = 1", ulps=1.0)
+    assert (outs[4][:1] != outs[1]).mean() < 0.05
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 20, 20, 512, 512), (2, 14, 14, 256, 1024)])
 def test_conv2d_bwd_data_split_k(N, H, W, Cin, Cout, capfd, monkeypatch):
     """rsu_conv2d_bwd_data_k: split reduction with the ReLU mask applied by the finish launch"""
