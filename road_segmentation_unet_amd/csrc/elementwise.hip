@@ -930,6 +930,17 @@ hipError_t ew_pack_many(const PackJob* jobs_dev, int njobs, int total_blocks, hi
 // from R2 ("B": conv backward-data, one buffer per concat source; transposed-conv forward, one buffer per tap).
 // ---------------------------------------------------------------------------------------------
 #define UP_EPB 4096   // floats per workgroup of a plain range
+// UP_NT (developer A/B switch): 1 = the gradient is read and the packed layouts are written with non-temporal hints (streamed once per
+// step); 2 = w and acc too
+#ifndef UP_NT
+#define UP_NT 0
+#endif
+namespace {
+__device__ __forceinline__ f32x4 up_ld_stream(const f32x4* p) { return UP_NT >= 1 ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ f32x4 up_ld_state(const f32x4* p) { return UP_NT >= 2 ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void up_st_state(f32x4* p, f32x4 v) { if (UP_NT >= 2) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void up_st_stream(u32x4* p, u32x4 v) { if (UP_NT >= 1) __builtin_nontemporal_store(v, p); else *p = v; }
+}  // namespace
 __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restrict__ jobs, int njobs, float lr, float mu, float gscale) {
     __shared__ int sj;
     __shared__ float tile[4][32][33];
@@ -980,13 +991,13 @@ __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restric
         f32x4 wv = {0.f, 0.f, 0.f, 0.f};
         if (cb < J.ncb && r < vr && c0 + c4 < J.R2) {   // (R2 is a multiple of 4: a float4 is inside or outside as a whole)
             const long i = (((long)tap * J.R1 + r0 + r) * J.R2 + c0 + c4) >> 2;
-            f32x4 a = ((f32x4*)J.acc)[i];
-            const f32x4 gv = ((const f32x4*)J.g)[i];
-            wv = ((f32x4*)J.w)[i];
+            f32x4 a = up_ld_state((const f32x4*)J.acc + i);
+            const f32x4 gv = up_ld_stream((const f32x4*)J.g + i);
+            wv = up_ld_state((const f32x4*)J.w + i);
             a = mu * a + gscale * gv;
             wv -= lr * a;
-            ((f32x4*)J.acc)[i] = a;
-            ((f32x4*)J.w)[i] = wv;
+            up_st_state((f32x4*)J.acc + i, a);
+            up_st_state((f32x4*)J.w + i, wv);
         }
         tile[q][r][c4] = wv[0]; tile[q][r][c4 + 1] = wv[1]; tile[q][r][c4 + 2] = wv[2]; tile[q][r][c4 + 3] = wv[3];
     }
@@ -1018,7 +1029,7 @@ __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restric
         const int ntl = D.ntiles[D.orient == 0 || D.tapmode == 2 ? 0 : seg];
         const long e = ((((long)chunk * D.ntap + tapd) * ntl + 2 * pair + tl) << 9) + lane * 8;
         u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        *(u32x4*)(base + e) = o;
+        up_st_stream((u32x4*)(base + e), o);
     }
 }
 int ew_update_job_blocks(const UpJob& j) {

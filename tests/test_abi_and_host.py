@@ -103,3 +103,13 @@ def test_packed_bytes_formula():
     assert _lib.lib().rsu_packed_bytes(9, 64, seg, 3) == 9 * 192 * 128 * 2
     seg = (ctypes.c_int * 2)(16, 16)
     assert _lib.lib().rsu_packed_bytes(9, 16, seg, 2) == 9 * 64 * 128 * 2
+
+
+def test_integration_md_counts_the_entry_points():
+    """INTEGRATION.md quotes the number of extern "C" entry points of include/rsu.h: the two must agree (it said 62 for 66)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "rsu.h")).read()
+    n = len(re.findall(r"^(?:int|size_t|const char\*) rsu_\w+\(", header, flags=re.M))
+    m = re.search(r"\((\d+) `extern \"C\"` functions", open(os.path.join(root, "INTEGRATION.md")).read())
+    assert m and int(m.group(1)) == n, (m and m.group(1), n)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (GPU box): tools/ab.sh name "libA.so libB.so ..." [reps] [extra bench args] -> gpurun_out/${ROUND:-r05}/ab_<name>.txt: bench.py `value` (default
+# two-stream schedule) under several builds of the library, alternating runs on one box; the first is the baseline
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPS=${3:-3}; EXTRA=${4:-}
+for rep in $(seq 1 $REPS); do
+  for lib in $2; do
+    RSU_LIB_PATH=$REPO/$lib timeout 600 python3 $REPO/bench.py --steps 30 --warmup 5 --no_cpu_baseline --sustain_seconds 0 $EXTRA 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
+print('$lib: %.1f patches/s | frac %.4f whole %.4f serial %.4f grouped %.4f | ' % (d['value'], r['frac'], r['whole_step_frac'], r['frac_serial_per_layer'], r['frac_single_stream_grouped']) + ' '.join('%s %.0f/%.3f' % (k[8:], v['tflops'], v['wall_ms_per_step']) for k, v in r['by_kernel'].items()))
+"
+  done
+done | tee $OUT/ab_$1.txt

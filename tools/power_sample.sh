@@ -1,14 +1,18 @@
 #!/bin/bash
-# usage (GPU box): tools/power_sample.sh -> gpurun_out/r03/power_during_bench.txt: rocm-smi power / clocks sampled while bench.py's sustained loop runs
-mkdir -p gpurun_out/r03
-python bench.py --steps 20 --warmup 3 --no_cpu_baseline --sustain_seconds 12 > /tmp/pb.json 2>/dev/null &
-BP=$!
-sleep 6
-for i in 1 2 3 4 5 6; do
-  rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | tr -s ' ' | sed 's/^/  /'
-  echo "  --"
-  sleep 1.5
-done > gpurun_out/r03/power_during_bench.txt
-wait $BP
-grep -o '"sustained": {[^}]*}' /tmp/pb.json >> gpurun_out/r03/power_during_bench.txt
-cat gpurun_out/r03/power_during_bench.txt
+# usage (GPU box): tools/power_sample.sh name [lib.so ...] -> gpurun_out/<ROUND>/power_<name>.txt: rocm-smi socket power / clocks sampled every ~0.3 s while
+# bench.py's sustained loop runs (12 s), once per library build given (default: the product build)
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT; cd $REPO
+NAME=$1; shift
+LIBS=${@:-road_segmentation_unet_amd/librsu_hip.so}
+for lib in $LIBS; do
+  echo "== $lib"
+  RSU_LIB_PATH=$REPO/$lib python3 bench.py --steps 20 --warmup 3 --no_cpu_baseline --sustain_seconds 12 > /tmp/pb.json 2>/dev/null &
+  BP=$!
+  sleep 7
+  for i in $(seq 1 14); do
+    rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed 's/.*: //' | tr '\n' ' '; echo
+    sleep 0.3
+  done
+  wait $BP
+  grep -o '"sustained": {[^}]*}' /tmp/pb.json
+done | tee $OUT/power_$NAME.txt

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: two timelines of tools/r05_timeline.sh side by side, kernel by kernel (per queue, in launch order): duration and idle gap of
+"""Developer tool: two timelines of tools/timeline.sh side by side, kernel by kernel (per queue, in launch order): duration and idle gap of
 each launch under build A and build B, and the totals per queue. usage: timeline_diff.py A.txt B.txt"""
 import sys, collections
 def load(p):
