@@ -6,10 +6,11 @@
 #                         launches)
 #   traffic.json          two --pmc passes (FETCH_SIZE / WRITE_SIZE) over the same command, stamped with the library's hash
 #   hbm_kernels.md        achieved GB/s of the bandwidth-bound kernels (tools/hbm_kernels_report.py)
+#   train_e2e.txt         tools/bench_train_e2e.py (the CLI's default --dropout 0.8, three input paths)
 #   predict.json          sliding-window inference: c5 (604 px, stride 12) and the reference's published config (608 px, stride 110)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${ROUND:-r05}
-rm -rf $OUT; mkdir -p $OUT
+mkdir -p $OUT $REPO/profiles/${ROUND:-r05}
 export RSU_AUTOTUNE_FILE=$OUT/autotune.json
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 unset RSU_AUTOTUNE_FILE
@@ -111,4 +112,5 @@ out = {"tool": "tools/bench_predict.py (ConvolutionalModel.predict on synthetic 
 json.dump(out, open("$OUT/predict.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
+timeout 900 python3 tools/bench_train_e2e.py 16 2 2>/dev/null | tail -40 > $OUT/train_e2e.txt   # ConvolutionalModel.train() at the CLI's default --dropout 0.8, input path included
 cut -c1-300 $OUT/bench.json
