@@ -68,7 +68,8 @@ def run_step(m, bucketer, lr, mu):
     m.forward_device()
     if bucketer is not None:
         bucketer.reset()
-    m.backward_device(m._inv_count)
+    # single device: the Momentum step + re-pack of the conv kernels rides on their weight-gradient launches (UNet.backward_device)
+    m.backward_device(m._inv_count, update=(lr, mu) if bucketer is None else None)
     if bucketer is not None:
         bucketer.finish()
     m.apply_momentum(lr, mu)

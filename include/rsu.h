@@ -212,6 +212,18 @@ size_t rsu_conv2d_bwd_weight_ws_floats(int Cin_total, int src_C, int Cout);
  * 32-pixel step); pass it with ONE of the sources of a concatenated input, NULL with the others. */
 int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
                           int Cin_total, int ci_off, int Cout, int dil, int ncu, rsu_stream_t stream);
+/* Conv2DBackpropFilter of one concat source AND tf_aerial_images.py:120-121 ApplyMomentum + the re-pack of the MFMA copies for the kernel
+ * rows that source owns, in the launch that sums the weight-gradient slabs (new; single-device training only: under data parallelism the
+ * gradient all-reduce sits between the two). Arguments as rsu_conv2d_bwd_weight, then: update_entry = HOST pointer to the table entry
+ * rsu_update_table_add made for this kernel (kind RSU_PACK_CONV_FWD, g = dw; its packed_bwd buffers must NOT be the ones a backward-data
+ * launch of the same step may still be reading on another stream: the host keeps two sets and swaps them per step), seg = index of
+ * `src` among the kernel's concat sources, (lr, mu, gscale) as rsu_update_table_run. The slabs are summed in the order of the plain entry
+ * point and every element sees the arithmetic of rsu_update_table_run: w, acc and the packed copies equal
+ * rsu_conv2d_bwd_weight -> rsu_update_table_run bit for bit. keep_grad != 0: dw is written as well (it always is when the launch needs no
+ * slabs); db (optional) is written as by rsu_conv2d_bwd_weight -- biases are updated by the host's table of the remaining variables. */
+int rsu_conv2d_bwd_weight_update(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
+                                 int Cin_total, int ci_off, int Cout, int dil, int ncu, const void* update_entry, int seg, float lr,
+                                 float mu, float gscale, int keep_grad, rsu_stream_t stream);
 /* Grouped weight gradients (new; TensorFlow's executor runs independent Conv2DBackpropFilter ops side by side, tf_aerial_images.py:120-121).
  * A weight-gradient launch that has the chip to itself writes one fp32 partial result per workgroup -- 75 MB of slabs per layer on
  * 256 CUs, read back by a reduce launch -- and a layer with few pixels cannot fill the chip. A GROUP runs up to

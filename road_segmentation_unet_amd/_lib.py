@@ -79,6 +79,7 @@ SIGNATURES = {
     "rsu_conv2d_bwd_data_k": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "rsu_conv2d_bwd_weight_ws_floats": (_sz, [_i, _i, _i]),
     "rsu_conv2d_bwd_weight": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_conv2d_bwd_weight_update": (_i, [_PS, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _f, _i, _vp]),
     "rsu_wgrad_group_table_bytes": (_sz, []),
     "rsu_wgrad_group_ws_floats": (_sz, []),
     "rsu_wgrad_group_plan": (_i, [ctypes.POINTER(RsuWgradJob), _i, _vp, _i, _i, _vp]),

@@ -62,6 +62,9 @@ struct UpJob {
 };
 int ew_update_job_blocks(const UpJob& j);
 hipError_t ew_update_pack_many(const UpJob* jobs_dev, int njobs, int total_blocks, float lr, float mu, float gscale, hipStream_t st);
+// the same pass over ONE R1 segment of one tensor, its gradient = the ordered sum of `nsplit` weight-gradient slabs (k_update_pack_seg)
+hipError_t ew_update_pack_seg(const UpJob& J, int seg, const float* slab, long stride, int nsplit, float* gout, float* out2, int n2, float lr, float mu,
+                              float gscale, hipStream_t st);
 hipError_t ew_extract_tiles(const float* imgs, float* tiles, int H, int S, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_add(const float* prob, float* acc, float* hits, int nimg, int H, int P, int stride, int pps, long t0, long ntiles, hipStream_t st);
 hipError_t ew_overlap_finish(const float* acc, const float* hits, float* out, long n, hipStream_t st);

@@ -941,44 +941,12 @@ __device__ __forceinline__ f32x4 up_ld_state(const f32x4* p) { return UP_NT >= 2
 __device__ __forceinline__ void up_st_state(f32x4* p, f32x4 v) { if (UP_NT >= 2) __builtin_nontemporal_store(v, p); else *p = v; }
 __device__ __forceinline__ void up_st_stream(u32x4* p, u32x4 v) { if (UP_NT >= 1) __builtin_nontemporal_store(v, p); else *p = v; }
 }  // namespace
-__global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restrict__ jobs, int njobs, float lr, float mu, float gscale) {
-    __shared__ int sj;
-    __shared__ float tile[4][32][33];
-    if (threadIdx.x < 64) {
-        // last job whose block_start <= blockIdx.x = (number of such jobs) - 1 (block_start ascends): every lane tests its share, ONE round
-        // trip to L2 instead of the seven dependent ones of a binary search by lane 0 (a third of a workgroup's short life)
-        int cnt = 0;
-        for (int j = threadIdx.x; j < njobs; j += 64) cnt += jobs[j].block_start <= (int)blockIdx.x ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (threadIdx.x == 0) sj = cnt - 1;
-    }
-    __syncthreads();
-    const UpJob& J = jobs[sj];
-    const int b = blockIdx.x - J.block_start;
-    if (J.kind == 0) {   // plain Momentum over a contiguous range (k_momentum's arithmetic)
-        const long n = J.n, n4 = n >> 2;
-        const long i0 = (long)b * (UP_EPB / 4);
-        for (int q = 0; q < UP_EPB / 4 / 256; ++q) {
-            const long i = i0 + q * 256 + threadIdx.x;
-            if (i < n4) {
-                f32x4 a = ((f32x4*)J.acc)[i], gv = ((const f32x4*)J.g)[i], wv = ((f32x4*)J.w)[i];
-                a = mu * a + gscale * gv;
-                wv -= lr * a;
-                ((f32x4*)J.acc)[i] = a;
-                ((f32x4*)J.w)[i] = wv;
-            }
-        }
-        if (b == 0 && threadIdx.x < (n & 3)) {
-            const long i = (n4 << 2) + threadIdx.x;
-            const float a = mu * J.acc[i] + gscale * J.g[i];
-            J.acc[i] = a;
-            J.w[i] -= lr * a;
-        }
-        return;
-    }
-    // ---- a packed tensor: workgroup b = (tap, row block rb, group of four column blocks cg)
-    const int ncg = (J.ncb + 3) >> 2;
-    const int cg = b % ncg, rb = (b / ncg) % J.nrb, tap = b / (ncg * J.nrb);
+// One workgroup of the packed-tensor path: block (tap, 32-row block rb, group cg of four 32-column blocks) of tensor J. `grad(i)` returns
+// the gradient float4 at float4 index i of the source tensor (k_update_pack_many: the gradient buffer; k_update_pack_seg: the ordered sum
+// of the weight-gradient slabs).
+template <typename GradFn>
+__device__ __forceinline__ void update_pack_block(const UpJob& J, float (*tile)[32][33], int tap, int rb, int cg, float lr, float mu, float gscale,
+                                                  GradFn grad) {
     int seg = 0;
     while (seg + 1 < J.nseg && rb >= J.seg_blk0[seg + 1]) ++seg;
     const int rbs = rb - J.seg_blk0[seg];                // 32-row block inside its segment
@@ -992,7 +960,7 @@ __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restric
         if (cb < J.ncb && r < vr && c0 + c4 < J.R2) {   // (R2 is a multiple of 4: a float4 is inside or outside as a whole)
             const long i = (((long)tap * J.R1 + r0 + r) * J.R2 + c0 + c4) >> 2;
             f32x4 a = up_ld_state((const f32x4*)J.acc + i);
-            const f32x4 gv = up_ld_stream((const f32x4*)J.g + i);
+            const f32x4 gv = grad(i);
             wv = up_ld_state((const f32x4*)J.w + i);
             a = mu * a + gscale * gv;
             wv -= lr * a;
@@ -1031,6 +999,100 @@ __global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restric
         u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
         up_st_stream((u32x4*)(base + e), o);
     }
+}
+__global__ void __launch_bounds__(256) k_update_pack_many(const UpJob* __restrict__ jobs, int njobs, float lr, float mu, float gscale) {
+    __shared__ int sj;
+    __shared__ float tile[4][32][33];
+    if (threadIdx.x < 64) {
+        // last job whose block_start <= blockIdx.x = (number of such jobs) - 1 (block_start ascends): every lane tests its share, ONE round
+        // trip to L2 instead of the seven dependent ones of a binary search by lane 0 (a third of a workgroup's short life)
+        int cnt = 0;
+        for (int j = threadIdx.x; j < njobs; j += 64) cnt += jobs[j].block_start <= (int)blockIdx.x ? 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (threadIdx.x == 0) sj = cnt - 1;
+    }
+    __syncthreads();
+    const UpJob& J = jobs[sj];
+    const int b = blockIdx.x - J.block_start;
+    if (J.kind == 0) {   // plain Momentum over a contiguous range (k_momentum's arithmetic)
+        const long n = J.n, n4 = n >> 2;
+        const long i0 = (long)b * (UP_EPB / 4);
+        for (int q = 0; q < UP_EPB / 4 / 256; ++q) {
+            const long i = i0 + q * 256 + threadIdx.x;
+            if (i < n4) {
+                f32x4 a = ((f32x4*)J.acc)[i], gv = ((const f32x4*)J.g)[i], wv = ((f32x4*)J.w)[i];
+                a = mu * a + gscale * gv;
+                wv -= lr * a;
+                ((f32x4*)J.acc)[i] = a;
+                ((f32x4*)J.w)[i] = wv;
+            }
+        }
+        if (b == 0 && threadIdx.x < (n & 3)) {
+            const long i = (n4 << 2) + threadIdx.x;
+            const float a = mu * J.acc[i] + gscale * J.g[i];
+            J.acc[i] = a;
+            J.w[i] -= lr * a;
+        }
+        return;
+    }
+    // ---- a packed tensor: workgroup b = (tap, row block rb, group of four column blocks cg)
+    const int ncg = (J.ncb + 3) >> 2;
+    const int cg = b % ncg, rb = (b / ncg) % J.nrb, tap = b / (ncg * J.nrb);
+    const float* gp = J.g;
+    update_pack_block(J, tile, tap, rb, cg, lr, mu, gscale, [gp](long i) { return up_ld_stream((const f32x4*)gp + i); });
+}
+// The same pass for ONE concat source (R1 segment `seg`) of ONE conv kernel, fed by the weight-gradient slabs of that source instead of a
+// finished gradient: the reduce launch of the slabs IS the update (the fp32 gradient is neither written nor re-read,
+// 8 of 28 B per weight; and the Momentum pass of these tensors leaves the tail of the step). Summation orders are those of
+// k_reduce_slabs / k_reduce_slabs_wide (sequential below 16 splits; else eight interleaved partial sums combined in order), so w, acc and
+// the packed copies equal reduce -> k_update_pack_many bit for bit. nsplit == 1: `slab` is the gradient the weight-gradient kernel wrote
+// in place. gout (optional): the reduced gradient is stored too (tests, hosts that log gradient norms). The last blocks reduce the n2
+// float4 items of the bias row (behind the taps of every slab) into out2, as k_reduce_slabs does.
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ slab, long stride, int nsplit, long e) {
+    if (nsplit < 16) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nsplit; ++z) t += *(const f32x4*)(slab + z * stride + e);
+        return t;
+    }
+    f32x4 part[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < nsplit; z0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (z0 + q < nsplit) part[q] += *(const f32x4*)(slab + (z0 + q) * stride + e);
+    }
+    f32x4 r = part[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) r += part[q];
+    return r;
+}
+__global__ void __launch_bounds__(256) k_update_pack_seg(const UpJob J, int seg, const float* __restrict__ slab, long stride, int nsplit,
+                                                         float* __restrict__ gout, float* __restrict__ out2, int n2, int tensor_blocks, float lr, float mu,
+                                                         float gscale) {
+    __shared__ float tile[4][32][33];
+    const int b = blockIdx.x;
+    if (b >= tensor_blocks) {   // the bias row
+        const int c4 = (b - tensor_blocks) * 256 + threadIdx.x;
+        if (c4 < n2) *(f32x4*)(out2 + c4 * 4) = slab_sum(slab, stride, nsplit, (long)J.ntap * J.R1 * J.R2 + c4 * 4);
+        return;
+    }
+    const int ncg = (J.ncb + 3) >> 2;
+    const int nrb_seg = (J.seg_c[seg] + 31) >> 5;
+    const int cg = b % ncg, rb = J.seg_blk0[seg] + (b / ncg) % nrb_seg, tap = b / (ncg * nrb_seg);
+    update_pack_block(J, tile, tap, rb, cg, lr, mu, gscale, [=](long i) {
+        const f32x4 g = slab_sum(slab, stride, nsplit, i * 4);
+        if (gout && nsplit > 1) *(f32x4*)(gout + i * 4) = g;
+        return g;
+    });
+}
+hipError_t ew_update_pack_seg(const UpJob& J, int seg, const float* slab, long stride, int nsplit, float* gout, float* out2, int n2, float lr, float mu,
+                              float gscale, hipStream_t st) {
+    const int tensor_blocks = J.ntap * ((J.seg_c[seg] + 31) / 32) * ((J.ncb + 3) >> 2);
+    const int bias_blocks = (out2 && nsplit > 1) ? (n2 + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_update_pack_seg, dim3(tensor_blocks + bias_blocks), dim3(256), 0, st, J, seg, slab, stride, nsplit, gout, out2, n2, tensor_blocks, lr, mu,
+                       gscale);
+    return hipGetLastError();
 }
 int ew_update_job_blocks(const UpJob& j) {
     if (j.kind == 0) return (int)((j.n + UP_EPB - 1) / UP_EPB);

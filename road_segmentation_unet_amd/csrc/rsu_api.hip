@@ -1017,8 +1017,10 @@ static void finish_wgrad(WgPrep& w, int nsplit, float* ws) {
     p.bslab = w.db ? (nsplit == 1 ? w.db : ws + w.main_elems) : nullptr;
     p.sbslab = w.dbs ? (nsplit == 1 ? w.dbs : ws + w.main_elems) : nullptr;
 }
+struct WgUpdate { const UpJob* job; int seg, keep_grad; float lr, mu, gscale; };
 static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_src_t* S, float* out, float* ws, int CsOut, int CfOut,
-                     int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu_arg, hipStream_t st, float* db = nullptr, float* dbs = nullptr) {
+                     int cs_off, int N, int ntap, int kw, int dil, int stride, int ncu_arg, hipStream_t st, float* db = nullptr, float* dbs = nullptr,
+                     const WgUpdate* upd = nullptr) {
     const int ncu = launch_ncu(ncu_arg);
     if (ncu < 0) return RSU_EINVAL;
     WgPrep w;
@@ -1034,7 +1036,21 @@ static int run_wgrad(int cfg, const void* F, int Hf, int Wf, int Cf, const rsu_s
         HIP_CHECK_RET(igemm_wgp64_launch(p, w.gx, w.gy, nslab, st));
     else
         HIP_CHECK_RET(igemm_wgrad_launch(w.cfg, ntap, p, w.gx, w.gy, nslab, st));
-    if (nslab > 1) {
+    if (upd) {
+        // the reduce launch IS the Momentum step + re-pack of the rows this source owns (k_update_pack_seg): nslab == 1 reads the gradient
+        // the kernel above wrote in place
+        // -- unless the launch has many slabs of a small kernel (>= 16: the 64- .. 256-channel layers): the update pass has one workgroup per
+        // 32 x 128 weights, far too few to stream 16 .. 128 slabs each (measured: c2 945 -> 750 patches/s); those keep the wide reduce launch and the
+        // update reads the finished gradient, L2-hot
+        const int fuse_max = env_int("RSU_FUSED_MAX_SPLIT", 15);
+        if (nslab > fuse_max) {
+            HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, w.extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
+            HIP_CHECK_RET(ew_update_pack_seg(*upd->job, upd->seg, out, 0, 1, nullptr, nullptr, 0, upd->lr, upd->mu, upd->gscale, st));
+        } else {
+            HIP_CHECK_RET(ew_update_pack_seg(*upd->job, upd->seg, nslab > 1 ? ws : out, nslab > 1 ? p.slab_stride : 0, nslab, upd->keep_grad ? out : nullptr,
+                                             db ? db : dbs, w.extra / 4, upd->lr, upd->mu, upd->gscale, st));
+        }
+    } else if (nslab > 1) {
         HIP_CHECK_RET(ew_reduce_slabs(ws, out, db ? db : dbs, w.extra / 4, nslab, p.slab_stride, ntap, CsOut, cs_off, S->C, CfOut, st));
     }
     return RSU_OK;
@@ -1050,6 +1066,21 @@ extern "C" int rsu_conv2d_bwd_weight(const rsu_src_t* src, const void* dz, float
     if (src->oy < 0 || src->ox < 0 || src->oy + Ho + 2 * dil > src->H || src->ox + Wo + 2 * dil > src->W || Wo < 2) return RSU_EINVAL;
     // F = dz (cf = co), S = layer input (cs = ci): slab[tap][ci][co] = HWIO
     return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db);
+}
+
+extern "C" int rsu_conv2d_bwd_weight_update(const rsu_src_t* src, const void* dz, float* dw, float* db, float* ws, int N, int Ho, int Wo,
+                                            int Cin_total, int ci_off, int Cout, int dil, int ncu, const void* update_entry, int seg, float lr,
+                                            float mu, float gscale, int keep_grad, rsu_stream_t stream) {
+    if (!src || !src->ptr || !dz || !dw || !ws || src->C % 8 || Cout % 8 || ci_off + src->C > Cin_total || (dil != 1 && dil != 2))
+        return RSU_EINVAL;
+    if (src->oy < 0 || src->ox < 0 || src->oy + Ho + 2 * dil > src->H || src->ox + Wo + 2 * dil > src->W || Wo < 2) return RSU_EINVAL;
+    const UpJob* J = (const UpJob*)update_entry;
+    // the entry must describe THIS kernel (rsu_update_table_add, kind RSU_PACK_CONV_FWD, g = dw) and `seg` the source at hand
+    if (!J || J->kind != 1 || J->ntap != 9 || J->R1 != Cin_total || J->R2 != Cout || J->g != dw || seg < 0 || seg >= J->nseg ||
+        J->seg_r0[seg] != ci_off || J->seg_c[seg] != src->C)
+        return RSU_EINVAL;
+    WgUpdate u{J, seg, keep_grad, lr, mu, gscale};
+    return run_wgrad(IGW_CFG_64x64, dz, Ho, Wo, Cout, src, dw, ws, Cin_total, Cout, ci_off, N, 9, 3, dil, 1, ncu, (hipStream_t)stream, db, nullptr, &u);
 }
 
 extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {

@@ -160,7 +160,9 @@ class ConvolutionalModel:
         net.forward_device(keep=float(opts.dropout))
         if self._bucketer is not None:
             self._bucketer.reset()
-        net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size))
+        # (single device: Momentum + re-pack of the conv kernels fused into their weight-gradient launches, rsu.h rsu_conv2d_bwd_weight_update)
+        net.backward_device(1.0 / (opts.batch_size * opts.patch_size * opts.patch_size),
+                            update=(opts.lr, opts.momentum) if self._bucketer is None else None)
         loss = net.loss_sum / (opts.batch_size * opts.patch_size * opts.patch_size)
         if self._bucketer is not None:
             self._bucketer.finish()

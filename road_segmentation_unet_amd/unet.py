@@ -132,6 +132,10 @@ class UNet:
             nside = max(1, len(os.environ.get("RSU_SPLIT_CHIP", _SPLIT_DEFAULT).split(",")) - 1)
             self.wstreams = [torch.cuda.Stream(device=self.device) for _ in range(nside)]
             self.wstream = self.wstreams[0]
+        # Momentum + re-pack fused into the weight-gradient side (backward_device(update=...), world size 1): the backward-data launches of
+        # step t read set `_pkset` of the backward-data packs while the fused updates of the same step write the other set
+        self._pkset, self.pk_alt, self._fused_tabs, self._fused, self._fused_pending = 0, {}, {}, None, None
+        self._update_tables, self._update_table = {}, None
         self.pool_code = {}
         self.prof = None       # list collecting (tag, algorithmic flops, start event, end event, CU share) when profiling
         self.on_grads = None   # callback(lo): every gradient at flat position >= lo is final (see dist.GradBucketer)
@@ -330,6 +334,7 @@ class UNet:
             self._pack_n, self._pack_blocks = idx, nb.value
             self._pack_table = torch.frombuffer(bytearray(host.raw[:esz * idx]), dtype=torch.uint8).to(self.device)
         call("rsu_pack_table_run", _ptr(self._pack_table), self._pack_n, self._pack_blocks, st)
+        self._pkset = 0   # (the pack table writes set 0 of the backward-data packs)
 
     # ------------------------------------------------------------------ forward
     def _stream(self):
@@ -578,6 +583,46 @@ class UNet:
         return steps
 
     # ------------------------------------------------------------------ backward
+    def _bwd_pack(self, kname, si, other=False):
+        """the backward-data pack of concat source si of conv kernel `kname` in the set the backward-data launches read now (other: the
+        set the fused updates of this step write; allocated on first use)"""
+        if (self._pkset == 0) != other:
+            return self.pk[kname, "bwd", si]
+        return self._bwd_pack_set1(kname, si)
+
+    def _fused_names(self):
+        """kernels whose Momentum step rides on their weight-gradient launches (backward_device(update=...)): every 3x3 conv kernel the
+        MFMA weight-gradient kernels serve -- all but the level-0 conv1 kernels (Cin = 3) and the transposed convs"""
+        return [n for n, (o, c, sh) in self._slices.items()
+                if o < self.n_live and n.endswith("kernel") and len(sh) == 4 and sh[0] == 3 and sh[2] != NUM_CHANNELS and not n.startswith("up_conv")]
+
+    def _fused_entry(self, kname):
+        """host pointer to the rsu_update_table_add entry of `kname` whose backward-data packs are the set NOT read in this step"""
+        tab = self._fused_tabs.get(kname)
+        lib = _lib.lib()
+        esz = lib.rsu_update_table_entry_bytes()
+        if tab is None:
+            sh = self._slices[kname][2]
+            segs = self._conv_sources_c(kname, sh)
+            host = ctypes.create_string_buffer(esz * 2)
+            keep = []
+            for st_ in (0, 1):   # entry st_ WRITES set st_
+                ptrs = [(self.pk[kname, "bwd", si] if st_ == 0 else self._bwd_pack_set1(kname, si)).data_ptr() for si in range(len(segs))]
+                bw = (ctypes.c_void_p * len(segs))(*ptrs)
+                keep.append(bw)
+                rc = lib.rsu_update_table_add(host, st_, 0, _ptr(self.w[kname]), _ptr(self.acc[kname]), _ptr(self.g[kname]), _ptr(self.pk[kname, "fwd"]), bw,
+                                              sh[2], sh[3], (ctypes.c_int * len(segs))(*segs), len(segs))
+                if rc != 1:
+                    raise _lib.RsuError("rsu_update_table_add(%s) failed: %d" % (kname, rc))
+            tab = self._fused_tabs[kname] = (host, keep)
+        return ctypes.c_void_p(ctypes.addressof(tab[0]) + esz * (1 - self._pkset))
+
+    def _bwd_pack_set1(self, kname, si):
+        t = self.pk_alt.get((kname, si))
+        if t is None:
+            t = self.pk_alt[kname, si] = torch.zeros_like(self.pk[kname, "bwd", si])
+        return t
+
     def _wgrad(self, name, srcs_t, dz, hout, dil=1):
         """dW (HWIO rows per source) + db of conv `name`; srcs_t = list of (tensor, window size). With grouping on (RSU_WG_GROUP) the
         launches are only queued here; _flush_wgrads sends a whole group to the side stream as one launch."""
@@ -606,12 +651,19 @@ class UNet:
             return
         with UNet._Side(self) as side:
             st = self._stream()
-            for t, win in srcs_t:
+            for si, (t, win) in enumerate(srcs_t):
                 s = _src(t, win, win)
                 db = _ptr(self.g[name + "/bias"]) if off == 0 else None  # BiasAddGrad rides along with the first source's launch
-                self._timed("conv3x3_bwd_weight", 2.0 * self.B * hout * hout * cout * t.shape[3] * 9, "rsu_conv2d_bwd_weight", ctypes.byref(s),
-                            _ptr(dz), _ptr(self.g[name + "/kernel"]), db, _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil,
-                            self._ncu, st)
+                fl = 2.0 * self.B * hout * hout * cout * t.shape[3] * 9
+                if self._fused is not None:
+                    # the launch that sums the slabs is the Momentum step + re-pack of the rows this source owns (rsu.h)
+                    lr, mu, keep_grad = self._fused
+                    self._timed("conv3x3_bwd_weight", fl, "rsu_conv2d_bwd_weight_update", ctypes.byref(s), _ptr(dz), _ptr(self.g[name + "/kernel"]), db,
+                                _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil, self._ncu, self._fused_entry(name + "/kernel"), si, lr, mu, 1.0,
+                                keep_grad, st)
+                else:
+                    self._timed("conv3x3_bwd_weight", fl, "rsu_conv2d_bwd_weight", ctypes.byref(s), _ptr(dz), _ptr(self.g[name + "/kernel"]), db,
+                                _ptr(side.ws), self.B, hout, hout, cin_total, off, cout, dil, self._ncu, st)
                 off += t.shape[3]
 
     def _wgradT(self, i, upin, dup, hh, nf):
@@ -671,18 +723,29 @@ class UNet:
         ho = hin - 2 * dil
         kws = self._kws()
         self._timed("conv3x3_bwd_data", 2.0 * self.B * ho * ho * cout * cnt * 9, "rsu_conv2d_bwd_data_k", _ptr(dz),
-                    _ptr(self.pk[name + "/kernel", "bwd", src_index]), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
+                    _ptr(self._bwd_pack(name + "/kernel", src_index)), _ptr(dx), _ptr(relu_src), accumulate, self.B, hin, hin, cnt, 0, cnt,
                     cout, dil, self._ncu, _ptr(kws), kws.numel() if kws is not None else 0, self._stream())
 
-    def backward_device(self, inv_count):
-        """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count)."""
+    def backward_device(self, inv_count, update=None, keep_grad=False):
+        """loss + all gradients for self.x / self.labels; forward_device() must have run. inv_count = 1 / (global pixel count).
+        update = (lr0, momentum): single-device training -- the MomentumOptimizer step (tf_aerial_images.py:120-121) and the re-pack of every
+        3x3 conv kernel ride on the kernel's weight-gradient launches (rsu.h rsu_conv2d_bwd_weight_update: the gradient is neither written
+        nor re-read, the pass leaves the tail of the step); apply_momentum(lr0, momentum) MUST follow and then only steps the remaining
+        variables. Same bits as the plain pair of calls. keep_grad: self.g of those kernels is written as well (it is not otherwise).
+        Ignored (the plain schedule runs) where the weight gradients are grouped, under a gradient exchange (on_grads) or RSU_FUSED_WGRAD=0."""
         B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
         keep = self.keep
         last = a[self.last_name]
         self._begin_split()
+        self._fused = self._fused_pending = None
+        if (update is not None and self.training and self._wg_group == 0 and self.on_grads is None and self.device.type == "cuda"
+                and os.environ.get("RSU_FUSED_WGRAD", "1") != "0" and os.environ.get("RSU_FUSED_UPDATE", "1") != "0"):
+            self._fused = (self.learning_rate(update[0]), float(update[1]), 1 if keep_grad else 0)
+            self._fused_pending = (float(update[0]), float(update[1]))
         try:
             self._backward_body(inv_count)
         finally:
+            self._fused = None
             self._end_split()   # (an exception inside must not leave later launches planned for a share of the chip)
         # ---- color_space_adjust (unet.py:22-23): its input gradient is never materialised (include/rsu.h, rsu_conv_first_bwd_weight):
         #   dW0[ci][cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gxc[t][ci][cj][co];  db0[cj] = 1/keep * sum_{t,co} W1[t][cj][co] * gm[t][cj][co]
@@ -831,13 +894,15 @@ class UNet:
         """tf.train.exponential_decay(lr, global_step, 1000, 0.95, staircase=True) (tf_aerial_images.py:116-117), float32"""
         return float(np.float32(lr0) * np.float32(0.95) ** np.float32(self.global_step // 1000))
 
-    def _build_update_table(self):
-        """the job table of rsu_update_table_run: one entry per conv / transposed-conv kernel (with its packed copies), the variables
-        between them (biases, colour adjust, the 1x1 head) as plain Momentum ranges; covers [0, n_live) of the flat buffers once"""
+    def _build_update_table(self, pkset=0, rest_only=False):
+        """the job table of rsu_update_table_run: one entry per conv / transposed-conv kernel (with its packed copies; the backward-data
+        packs of set `pkset`), the variables between them (biases, colour adjust, the 1x1 head) as plain Momentum ranges; covers [0, n_live)
+        of the flat buffers once. rest_only: without the kernels whose step rode on their weight-gradient launches (_fused_names)."""
         lib = _lib.lib()
         if not hasattr(self, "pk"):
             self.repack()
-        entries, plain_lo, pos = [], None, 0   # ("plain", lo, hi) / ("tensor", name, kind)
+        skip = set(self._fused_names()) if rest_only else set()
+        entries, plain_lo = [], None   # ("plain", lo, hi) / ("tensor", name, kind)
         live = sorted(((o, c, n, sh) for n, (o, c, sh) in self._slices.items() if o < self.n_live), key=lambda t: t[0])
         for o, c, n, sh in live:
             packed = n.endswith("kernel") and (n.startswith("up_conv") or (len(sh) == 4 and sh[0] == 3))
@@ -847,8 +912,8 @@ class UNet:
             if plain_lo is not None:
                 entries.append(("plain", plain_lo, o))
                 plain_lo = None
-            entries.append(("tensor", n, sh))
-            pos = o + c
+            if n not in skip:
+                entries.append(("tensor", n, sh))
         if plain_lo is not None:
             entries.append(("plain", plain_lo, self.n_live))
         esz = lib.rsu_update_table_entry_bytes()
@@ -870,27 +935,41 @@ class UNet:
                     rc = lib.rsu_update_table_add(host, idx, 4, w, a, g, _ptr(self.pk[n, "fwd"]), None, 3, sh[3], None, 0)
                 else:
                     segs = self._conv_sources_c(n, sh)
-                    bw = (ctypes.c_void_p * len(segs))(*[self.pk[n, "bwd", si].data_ptr() for si in range(len(segs))]) if self.training else None
+                    packs = [self.pk[n, "bwd", si] if pkset == 0 else self._bwd_pack_set1(n, si) for si in range(len(segs))]
+                    bw = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for t in packs]) if self.training else None
                     rc = lib.rsu_update_table_add(host, idx, 0, w, a, g, _ptr(self.pk[n, "fwd"]), bw, sh[2], sh[3], (ctypes.c_int * len(segs))(*segs), len(segs))
                 keep.append(bw)
             if rc != 1:
                 raise _lib.RsuError("rsu_update_table_add(%s) failed: %d" % (e[1], rc))
         nb = ctypes.c_int(0)
         _lib.check(lib.rsu_update_table_finish(host, len(entries), ctypes.byref(nb)), "rsu_update_table_finish")
-        self._update_table = (torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device), len(entries), nb.value)
+        tab = (torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device), len(entries), nb.value)
+        self._update_tables[pkset, rest_only] = tab
+        if pkset == 0 and not rest_only:
+            self._update_table = tab   # (the name tools and probes know)
+        return tab
 
     def apply_momentum(self, lr0, momentum, gscale=1.0):
         """MomentumOptimizer step on every live variable (tf_aerial_images.py:120-121) and the re-pack of the bf16 MFMA copies, in one
-        pass over the parameters (rsu_update_table_run; RSU_FUSED_UPDATE=0: rsu_momentum_step, then the batched re-pack -- same bits)."""
+        pass over the parameters (rsu_update_table_run; RSU_FUSED_UPDATE=0: rsu_momentum_step, then the batched re-pack -- same bits).
+        Behind backward_device(update=(lr0, momentum)) the 3x3 conv kernels have been stepped already: only the other variables are."""
+        pending, self._fused_pending = self._fused_pending, None
+        if pending is not None:
+            if pending != (float(lr0), float(momentum)) or gscale != 1.0:
+                raise _lib.RsuError("apply_momentum(%r, %r, gscale=%r) behind backward_device(update=%r): the step already applied to the conv kernels "
+                                    "used other hyper-parameters" % (lr0, momentum, gscale, pending))
+            tab = self._update_tables.get((0, True)) or self._build_update_table(0, True)
+            call("rsu_update_table_run", _ptr(tab[0]), tab[1], tab[2], self.learning_rate(lr0), momentum, gscale, self._stream())
+            self._pkset = 1 - self._pkset   # the fused updates wrote the other set of backward-data packs: the next step reads it
+            self.global_step += 1
+            return
         if os.environ.get("RSU_FUSED_UPDATE", "1") == "0":
             call("rsu_momentum_step", _ptr(self.flat_w), _ptr(self.flat_acc), _ptr(self.flat_g), self.learning_rate(lr0), momentum, gscale,
                  self.n_live, self._stream())
             self.global_step += 1
             self.repack()
             return
-        if getattr(self, "_update_table", None) is None:
-            self._build_update_table()
-        tab = self._update_table
+        tab = self._update_tables.get((self._pkset, False)) or self._build_update_table(self._pkset, False)
         call("rsu_update_table_run", _ptr(tab[0]), tab[1], tab[2], self.learning_rate(lr0), momentum, gscale, self._stream())
         self.global_step += 1
 

@@ -342,3 +342,41 @@ def test_c2_full_size_gradients_match_oracle(monkeypatch):
         print("c2 B=4 (wgrad stream %s) vs oracle: worst gradient rel err %s %.2e, prob %.2e" % (wgrad_stream, w4, errs4[w4], d4))
         for n, e in errs4.items():
             assert e <= C2_GRAD_REL_MAX, (wgrad_stream, n, e)
+
+
+def test_c2_benchmarked_batch_of_four_distinct_patches_match_oracle(monkeypatch):
+    """the batch bench.py times is FOUR DIFFERENT patches, and four copies of one patch cannot see a batch-stride or
+    image-border bug of the N = 4 plans (strips, pixel splits and reduction slices that differ from N = 1) that reads image 0 for image b.
+    Four seeded patches with their own labels go through the tuned B = 4 step in both schedules of the backward pass and are checked
+    against ONE oracle run over the same batch (the oracle's loss is the mean over the batch, its gradients the gradients of that mean):
+    loss 2e-4, every image's probability map 4e-3, every gradient tensor 2e-2 relative Frobenius -- the one-patch tolerances."""
+    L, root, P = C2
+    S, X4, lab4, params = _setup(L, root, P, 4, False, seed=47)
+    assert float(np.abs(X4[1] - X4[0]).max()) > 0.5 and (lab4[2] != lab4[3]).any()
+    emu = U.loss_and_grads(params, X4, lab4, L, root, False, emulate_bf16=True)
+    for b in range(1, 4):   # the oracle's own maps differ per image: the comparison below is not blind to a swap
+        assert float(np.abs(emu[1][b] - emu[1][0]).max()) > 1e-2
+    for wgrad_stream in ("1", "0"):
+        monkeypatch.setenv("RSU_WGRAD_STREAM", wgrad_stream)
+        m4 = UNet(L, root, False, 4, P, params=params, training=True)
+        assert bool(m4.wstreams) == (wgrad_stream == "1")
+        m4.tune()
+        m4.x.copy_(torch.from_numpy(X4))
+        m4.labels.copy_(torch.from_numpy(lab4))
+        m4.forward_device()
+        m4.backward_device(1.0 / (4 * P * P))
+        torch.cuda.synchronize()
+        loss4 = float(m4.loss_sum.item()) / (4 * P * P)
+        prob4 = m4.prob.cpu().numpy()
+        g4 = {n: m4.g[n].detach().cpu().numpy().copy() for n in m4.names}
+        del m4
+        assert abs(loss4 - emu[0]) <= 2e-4 * abs(emu[0]), (wgrad_stream, loss4, emu[0])
+        d4 = [float(np.abs(prob4[b] - emu[1][b]).max()) for b in range(4)]
+        assert max(d4) <= C2_FWD_EMU_MAX, (wgrad_stream, d4)
+        errs4 = _rel_errs(g4, emu[2])
+        w4 = max(errs4, key=errs4.get)
+        record("c2_batch4_distinct_vs_oracle_wgrad_stream_" + wgrad_stream, loss_hip=loss4, loss_emu=emu[0], prob_d_emu_max_per_image=d4,
+               worst_grad_rel_err=errs4[w4], worst_grad_tensor=w4)
+        print("c2 B=4, four distinct patches (wgrad stream %s) vs oracle: worst gradient rel err %s %.2e, prob %s" % (wgrad_stream, w4, errs4[w4], d4))
+        for n, e in errs4.items():
+            assert e <= C2_GRAD_REL_MAX, (wgrad_stream, n, e)

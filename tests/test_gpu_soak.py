@@ -141,3 +141,41 @@ def test_fused_update_equals_momentum_then_repack(L, root, dilated, P, monkeypat
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for k in a[2]:
         assert torch.equal(a[2][k].view(torch.int16), b[2][k].view(torch.int16)), k
+
+
+@pytest.mark.parametrize("L,root,dilated,P,B", [(5, 64, False, 388, 4), (6, 64, True, 388, 1), (4, 32, False, 204, 2), (3, 16, True, 60, 2), (3, 64, True, 28, 2)])
+def test_update_fused_into_the_weight_gradient_side_equals_the_plain_step(L, root, dilated, P, B):
+    """backward_device(update=(lr, mu)) + apply_momentum (rsu_conv2d_bwd_weight_update: the launch that sums a conv kernel's weight-gradient
+    slabs applies Momentum and writes both packed layouts, the backward-data packs double-buffered) against the plain backward_device +
+    apply_momentum: weights, Momentum slots, the forward packs and the backward-data packs the NEXT step reads, bit for bit over three
+    steps -- on c2 and c3 at full size and on small nets with 16-channel concat segments, dilated twins and launches
+    that need no slabs. The third step of the fused run also asks for the gradients (keep_grad) and must give the plain run's."""
+    from road_segmentation_unet_amd.unet import UNet
+
+    def run(fused):
+        m = UNet(L, root, dilated, B, P, seed=17, training=True)
+        m.tune()
+        g = torch.Generator(device="cpu").manual_seed(6)
+        for step in range(3):
+            m.x.copy_(torch.rand((B, m.S, m.S, 3), generator=g))
+            m.labels.copy_((torch.rand((B, P, P), generator=g) < 0.2).to(torch.int64))
+            m.forward_device()
+            if fused:
+                m.backward_device(1.0 / (B * P * P), update=(0.05, 0.9), keep_grad=(step == 2))
+                assert m._fused_pending is not None, "the fused schedule did not run"
+            else:
+                m.backward_device(1.0 / (B * P * P))
+            m.apply_momentum(0.05, 0.9)
+        torch.cuda.synchronize()
+        packs = {k: v.clone() for k, v in m.pk.items() if k[1] == "fwd" or len(k) == 2}
+        for k in m.pk:
+            if len(k) == 3:
+                packs[k] = m._bwd_pack(k[0], k[2]).clone()
+        return m.flat_w.clone(), m.flat_acc.clone(), packs, m.flat_g.clone(), m.global_step
+
+    a, b = run(True), run(False)
+    assert a[4] == b[4] == 3
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in b[2]:
+        assert torch.equal(a[2][k].view(torch.int16), b[2][k].view(torch.int16)), k
+    assert torch.equal(a[3], b[3])

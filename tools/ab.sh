@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/ab.sh name "libA.so libB.so ..." [reps] [extra bench args] -> gpurun_out/${ROUND:-r05}/ab_<name>.txt: bench.py `value` (default
+# usage (GPU box): tools/ab.sh name "libA.so libB.so ..." [reps] [extra bench args] -> gpurun_out/${ROUND:-r06}/ab_<name>.txt: bench.py `value` (default
 # two-stream schedule) under several builds of the library, alternating runs on one box; the first is the baseline
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT
 REPS=${3:-3}; EXTRA=${4:-}
 for rep in $(seq 1 $REPS); do
   for lib in $2; do

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/abenv.sh name "ENV_A" "ENV_B" [reps] [extra bench args] -> gpurun_out/${ROUND:-r05}/abenv_<name>.txt: bench.py `value` under two
+# usage (GPU box): tools/abenv.sh name "ENV_A" "ENV_B" [reps] [extra bench args] -> gpurun_out/${ROUND:-r06}/abenv_<name>.txt: bench.py `value` under two
 # environment settings (space-separated VAR=value lists; "X=1" for none), alternating runs on one box
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT
 REPS=${4:-3}; EXTRA=${5:-}
 for rep in $(seq 1 $REPS); do
   for tag in A B; do

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/fixed_ab.sh name "libA.so libB.so ..." ["H,Cin,Cout,cfg ..."] [reps] -> gpurun_out/${ROUND:-r05}/fixed_<name>.txt: forward / backward-data
+# usage (GPU box): tools/fixed_ab.sh name "libA.so libB.so ..." ["H,Cin,Cout,cfg ..."] [reps] -> gpurun_out/${ROUND:-r06}/fixed_<name>.txt: forward / backward-data
 # times of single layers at FIXED tile shapes (tools/pp_fixed.py) under several builds of the library, alternating on one box
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT; cd $REPO
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT; cd $REPO
 SPECS=${3:-"570,64,64,1 570,64,64,5 282,128,128,0 282,128,128,4 138,256,256,0 392,128,64,1 390,64,64,5 198,128,128,0 66,512,512,0"}
 REPS=${4:-3}
 for rep in $(seq 1 $REPS); do

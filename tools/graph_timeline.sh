@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/graph_timeline.sh -> gpurun_out/<ROUND>/graph_timeline.txt: rocprofv3 --kernel-trace of tools/graph_probe.py; one eager step and one
 # hipGraph replay of the same c2 training step side by side: queues used, busy time and idle gaps per queue, kernel durations
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_graph
 rocprofv3 --kernel-trace -d $OUT/prof_graph -o t -- python3 $REPO/tools/graph_probe.py > $OUT/graph_probe.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): tools/measure.sh  -> gpurun_out/${ROUND:-r05}/: the round's measured artefacts (copied to profiles/${ROUND:-r05}/ afterwards)
+# usage (GPU box): tools/measure.sh  -> gpurun_out/${ROUND:-r06}/: the round's measured artefacts (copied to profiles/${ROUND:-r06}/ afterwards)
 #   bench.json            python bench.py (default flags: two-stream timed region, roofline = chip time of that schedule, CPU baselines)
 #   bench_c3.json / bench_c4.json   python bench.py --workload c3 / c4
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the same command in the DEFAULT two-stream schedule (tile shapes imported: no timing
@@ -9,8 +9,8 @@
 #   train_e2e.txt         tools/bench_train_e2e.py (the CLI's default --dropout 0.8, three input paths)
 #   predict.json          sliding-window inference: c5 (604 px, stride 12) and the reference's published config (608 px, stride 110)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/${ROUND:-r05}
-mkdir -p $OUT $REPO/profiles/${ROUND:-r05}
+OUT=$REPO/gpurun_out/${ROUND:-r06}
+mkdir -p $OUT $REPO/profiles/${ROUND:-r06}
 export RSU_AUTOTUNE_FILE=$OUT/autotune.json
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 unset RSU_AUTOTUNE_FILE
@@ -94,8 +94,8 @@ PY
 python3 $REPO/tools/hbm_kernels_report.py $OUT/kernel_stats.csv $(cat $OUT/nsteps.txt) > $OUT/hbm_kernels.md; cat $OUT/hbm_kernels.md
 rm -rf $OUT/prof $OUT/pmc
 cd $REPO
-# the contract line once more, now that traffic.json carries this library's hash (bench.py reads profiles/${ROUND:-r05}/traffic.json): this is bench.json
-cp $OUT/traffic.json $REPO/profiles/${ROUND:-r05}/traffic.json
+# the contract line once more, now that traffic.json carries this library's hash (bench.py reads profiles/${ROUND:-r06}/traffic.json): this is bench.json
+cp $OUT/traffic.json $REPO/profiles/${ROUND:-r06}/traffic.json
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/bench_predict.py --L 6 --dilated --images 1 --stride 12 --size 604 --batch 8 2>/dev/null | tail -1 > $OUT/predict_c5.txt
 python3 tools/bench_predict.py --L 6 --dilated --images 10 --stride 110 --size 608 --batch 1 2>/dev/null | tail -1 > $OUT/predict_ref.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_wgrad_layers.sh -> gpurun_out/<ROUND>/wgrad_traffic_by_layer.txt: HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, two --pmc passes) of every
 # weight-gradient launch of one c2 backward pass, in launch order, beside the launch's algorithmic bytes (dz + layer input read once, one slab per workgroup written)
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/pmcw
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcw -o rd -- python3 $REPO/bench.py --steps 2 --warmup 1 --no_cpu_baseline --sustain_seconds 0 --prime_seconds 0 > $OUT/pmcw_rd.log 2>&1

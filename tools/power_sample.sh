@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/power_sample.sh name [lib.so ...] -> gpurun_out/<ROUND>/power_<name>.txt: rocm-smi socket power / clocks sampled every ~0.3 s while
 # bench.py's sustained loop runs (12 s), once per library build given (default: the product build)
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT; cd $REPO
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT; cd $REPO
 NAME=$1; shift
 LIBS=${@:-road_segmentation_unet_amd/librsu_hip.so}
 for lib in $LIBS; do

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/timeline.sh <tag> [env assignments...] -> gpurun_out/${ROUND:-r05}/timeline_<tag>.txt: start / end / duration / queue of every kernel of
+# usage (GPU box): tools/timeline.sh <tag> [env assignments...] -> gpurun_out/${ROUND:-r06}/timeline_<tag>.txt: start / end / duration / queue of every kernel of
 # one steady-state step of bench.py's timed loop (rocprofv3 --kernel-trace), with the idle gap in front of each kernel on its queue
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r05}; mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/${ROUND:-r06}; mkdir -p $OUT
 TAG=$1; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
