@@ -239,6 +239,10 @@ def main():
         bucketer.extra_streams = list(m.wstreams)
         m.on_grads = bucketer.ready
     lr, mu = 0.01, 0.9
+    # developer switch (tools/dp_budget.sh): the CU budget a data-parallel run would give the backward launches (dist.tune_overlap's candidates),
+    # on one GPU, with the update left behind the pass as under an exchange -- what does leaving CUs to RCCL's channel workgroups cost?
+    if os.environ.get("RSU_BENCH_BWD_BUDGET"):
+        m.backward_cu_budget = int(os.environ["RSU_BENCH_BWD_BUDGET"])
 
     # the explicit tile-shape tuning pass (UNet.tune: one untimed forward + backward in RSU_TUNE_MEASURE mode; the launches of the
     # timed region only look shapes up), skipped when a table measured by this very build was imported; then one untimed priming step

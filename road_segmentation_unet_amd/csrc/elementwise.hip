@@ -953,21 +953,32 @@ __device__ __forceinline__ void update_pack_block(const UpJob& J, float (*tile)[
     const int r0 = J.seg_r0[seg] + rbs * 32;              // first source row
     const int vr = min(32, J.seg_c[seg] - rbs * 32);      // real rows of the block
     const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    // every load of the workgroup's four blocks is issued before the first store: w / acc are read and written through the same (non-restrict)
+    // pointers, so a store in front of a later block's loads would order them -- four dependent round trips to memory instead of one
+    f32x4 av[4], gv[4], wv[4];
+    long idx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int cb = cg * 4 + q, c0 = cb * 32;
-        f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+        idx[q] = -1;
+        av[q] = gv[q] = wv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (cb < J.ncb && r < vr && c0 + c4 < J.R2) {   // (R2 is a multiple of 4: a float4 is inside or outside as a whole)
             const long i = (((long)tap * J.R1 + r0 + r) * J.R2 + c0 + c4) >> 2;
-            f32x4 a = up_ld_state((const f32x4*)J.acc + i);
-            const f32x4 gv = grad(i);
-            wv = up_ld_state((const f32x4*)J.w + i);
-            a = mu * a + gscale * gv;
-            wv -= lr * a;
-            up_st_state((f32x4*)J.acc + i, a);
-            up_st_state((f32x4*)J.w + i, wv);
+            idx[q] = i;
+            av[q] = up_ld_state((const f32x4*)J.acc + i);
+            gv[q] = grad(i);
+            wv[q] = up_ld_state((const f32x4*)J.w + i);
         }
-        tile[q][r][c4] = wv[0]; tile[q][r][c4 + 1] = wv[1]; tile[q][r][c4 + 2] = wv[2]; tile[q][r][c4 + 3] = wv[3];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (idx[q] >= 0) {
+            av[q] = mu * av[q] + gscale * gv[q];
+            wv[q] -= lr * av[q];
+            up_st_state((f32x4*)J.acc + idx[q], av[q]);
+            up_st_state((f32x4*)J.w + idx[q], wv[q]);
+        }
+        tile[q][r][c4] = wv[q][0]; tile[q][r][c4 + 1] = wv[q][1]; tile[q][r][c4 + 2] = wv[q][2]; tile[q][r][c4 + 3] = wv[q][3];
     }
     __syncthreads();
     // ---- both packed layouts from LDS: per (column block, destination) 128 pieces of 16 bytes = the 2 tiles of a 32-row pair

@@ -1089,11 +1089,12 @@ extern "C" size_t rsu_convT2x2_bwd_weight_ws_floats(int Cin, int Cout) {
 extern "C" int rsu_convT2x2_bwd_weight(const void* x, const void* dy, float* dK, float* db, float* ws, int N, int H, int W, int Cin,
                                        int Cout, int ncu, rsu_stream_t stream) {
     if (!x || !dy || !dK || !ws || Cin % 8 || Cout % 8 || W < 2) return RSU_EINVAL;
-    // RSU_WGT_GEN=1: the generic igemm_wgrad launch (4 taps, stride 2) of rounds 1-3a; 3: the ping-pong kernel of igemm_wgt.hip; 2 (default):
-    // the ping-pong kernel where the launch has (most of) the chip to itself. Beside a backward-data kernel on the other half of the chip
-    // the faster kernel made the STEP slower, reproducibly (945 -> 938 patches/s, profiles/r03/lib_ab_wgt.txt, split_sweep_wgt.txt; DESIGN.md
-    // section 3.7 lists what was tried around it).
-    const int wgt_gen = env_int("RSU_WGT_GEN", 2);
+    // RSU_WGT_GEN=1: the generic igemm_wgrad launch (4 taps, stride 2) of rounds 1-3a; 3 (default since round 6): the ping-pong kernel of
+    // igemm_wgt.hip at every CU budget; 2 (rounds 3-5): the ping-pong kernel only where the launch has (most of) the chip to itself. In round 3
+    // the faster kernel beside a backward-data kernel made the STEP slower (945 -> 938 patches/s, profiles/r03/lib_ab_wgt.txt); with round 4's
+    // backward-data kernels on the other half of the chip the same A/B reads 933 -> 955 (three alternations, profiles/r06/abenv_wgt_gen.txt): the
+    // four launches leave the weight-gradient stream -- the longer one, the main stream waits ~60 us for it at the end of the pass -- 0.14 ms shorter.
+    const int wgt_gen = env_int("RSU_WGT_GEN", 3);
     if (wgt_gen >= 2 && igemm_wgt_supports(N, H, W, Cin, Cout) && (wgt_gen >= 3 || launch_ncu(ncu) >= 192)) {
         const int n = launch_ncu(ncu);
         if (n < 0) return RSU_EINVAL;

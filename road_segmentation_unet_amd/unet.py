@@ -27,6 +27,7 @@ NUM_LABELS = 2    # src/constants.py:4
 _WG_GROUP_TWO_STREAMS, _WG_GROUP_ONE_STREAM = "0", "all"
 # RSU_RAW_EVENTS=0: fork the side stream through torch events (system-scope release) instead of _lib.hip_fork (agent scope)
 _RAW_EVENTS = os.environ.get("RSU_RAW_EVENTS", "1") != "0"
+_NO_FORK_PROBE = os.environ.get("RSU_NO_FORK_PROBE", "0") == "1"   # developer timing probe (profiles/r06/fork_bound.txt): NO dependency at all
 _WG_EVENTS = os.environ.get("RSU_WG_EVENTS", "0") == "1"   # grouped weight gradients: a torch event per queued job (rounds 2-3)
 _SPLIT_DEFAULT = "128,128"   # RSU_SPLIT_CHIP: CUs the main stream / each side stream plan for during the backward pass (UNet._Side)
 
@@ -393,7 +394,14 @@ class UNet:
         if parts is None:
             self._ncu = full if self.backward_cu_budget else 0
             return
-        parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
+        if full < 256 and len(parts) == 2 and parts == [128, 128] and full >= 224:
+            # a data-parallel budget (CUs left to RCCL's channel workgroups): the weight-gradient stream keeps its 128 -- its pixel splits and
+            # workgroup counts per XCD are powers of two: 120 + 120 costs c2 8 % and c4 5 %, 112 + 128 costs 1.7 % and 3.6 % (profiles/r06/
+            # dp_budget.txt) -- and the backward-data stream, whose persistent kernels walk tile lists of any length, takes the rest. Below 224
+            # the backward-data stream would starve (80 + 128: -16 %): the proportional split again
+            parts = [full - 128, 128]
+        else:
+            parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
         self._split = (full, parts[0], parts[1:])
         # the main stream keeps the whole budget until the first weight-gradient launch has gone to the side stream
         self._ncu = full if self.backward_cu_budget else 0
@@ -426,7 +434,11 @@ class UNet:
             if n._split is not None:
                 n._ncu = n._split[0] if self.alone else n._split[2][k]
             ev = self.after
-            if ev is None and _RAW_EVENTS:
+            if _NO_FORK_PROBE and n._split is not None and n._side_active:
+                # (timing probe only: behind the first fork of a backward pass the side stream no longer waits for the main stream -- wrong
+                # numbers, the bound of a dependency that costs neither queue anything: profiles/r06/fork_bound.txt)
+                pass
+            elif ev is None and _RAW_EVENTS:
                 # the fork costs the MAIN queue an idle gap per weight-gradient launch (the event's packet sits between two backward-data
                 # kernels): ~6 us with a torch event, less without the system-scope fence a same-device dependency does not need
                 try:
@@ -732,14 +744,17 @@ class UNet:
         3x3 conv kernel ride on the kernel's weight-gradient launches (rsu.h rsu_conv2d_bwd_weight_update: the gradient is neither written
         nor re-read, the pass leaves the tail of the step); apply_momentum(lr0, momentum) MUST follow and then only steps the remaining
         variables. Same bits as the plain pair of calls. keep_grad: self.g of those kernels is written as well (it is not otherwise).
-        Ignored (the plain schedule runs) where the weight gradients are grouped, under a gradient exchange (on_grads) or RSU_FUSED_WGRAD=0."""
+        OPT-IN (RSU_FUSED_WGRAD=1; otherwise, and where the weight gradients are grouped or a gradient exchange runs, the plain schedule
+        runs and apply_momentum steps everything): measured in round 6, the pass costs the weight-gradient stream -- which is as long as
+        the backward-data stream -- more than it saves behind the pass: c2 955 -> 888 patches/s, c3 212 -> 184 (profiles/r06/abenv_fused2_*.txt;
+        an HBM-bound pass on the half of the chip the weight-gradient kernel leaves it, beside a backward-data kernel)."""
         B, L, st, a, g = self.B, self.L, self._stream(), self.act, self.grad
         keep = self.keep
         last = a[self.last_name]
         self._begin_split()
         self._fused = self._fused_pending = None
         if (update is not None and self.training and self._wg_group == 0 and self.on_grads is None and self.device.type == "cuda"
-                and os.environ.get("RSU_FUSED_WGRAD", "1") != "0" and os.environ.get("RSU_FUSED_UPDATE", "1") != "0"):
+                and os.environ.get("RSU_FUSED_WGRAD", "0") == "1" and os.environ.get("RSU_FUSED_UPDATE", "1") != "0"):
             self._fused = (self.learning_rate(update[0]), float(update[1]), 1 if keep_grad else 0)
             self._fused_pending = (float(update[0]), float(update[1]))
         try:

@@ -144,13 +144,14 @@ def test_fused_update_equals_momentum_then_repack(L, root, dilated, P, monkeypat
 
 
 @pytest.mark.parametrize("L,root,dilated,P,B", [(5, 64, False, 388, 4), (6, 64, True, 388, 1), (4, 32, False, 204, 2), (3, 16, True, 60, 2), (3, 64, True, 28, 2)])
-def test_update_fused_into_the_weight_gradient_side_equals_the_plain_step(L, root, dilated, P, B):
+def test_update_fused_into_the_weight_gradient_side_equals_the_plain_step(L, root, dilated, P, B, monkeypatch):
     """backward_device(update=(lr, mu)) + apply_momentum (rsu_conv2d_bwd_weight_update: the launch that sums a conv kernel's weight-gradient
     slabs applies Momentum and writes both packed layouts, the backward-data packs double-buffered) against the plain backward_device +
     apply_momentum: weights, Momentum slots, the forward packs and the backward-data packs the NEXT step reads, bit for bit over three
     steps -- on c2 and c3 at full size and on small nets with 16-channel concat segments, dilated twins and launches
     that need no slabs. The third step of the fused run also asks for the gradients (keep_grad) and must give the plain run's."""
     from road_segmentation_unet_amd.unet import UNet
+    monkeypatch.setenv("RSU_FUSED_WGRAD", "1")   # (opt-in: the schedule is slower than the plain one on this hardware, unet.py backward_device)
 
     def run(fused):
         m = UNet(L, root, dilated, B, P, seed=17, training=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer timing of the conv ops at the BASELINE config shapes (developer tool, runs on the GPU box).
-usage: python tools/bench_layers.py [--L 5 --root 64 --P 388 --B 4] [--cfgs -1,0,1,2,3,4] [--ops fwd,bwd,wg]"""
+usage: python tools/bench_layers.py [--L 5 --root 64 --P 388 --B 4] [--cfgs -1,0,1,2,3,4] [--ops fwd,bwd,wg] [--ncu 128] [--cold]"""
 import argparse
 import ctypes
 import os
@@ -19,9 +19,25 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_COLD = None   # --cold: a 512-MiB buffer written between repetitions, so that a layer's weights and inputs come from HBM as they do in the step
+
+
 def timeit(fn, reps=5):
     fn()
     torch.cuda.synchronize()
+    if _COLD is not None:
+        # every repetition behind a write that displaces L2 and the Infinity Cache (256 MB): the in-step condition (VERDICT r5 "What's weak" 5:
+        # hot-cache tables overstate in-step rates by 13-47 %); timed one by one, the flush is outside the events
+        tot = 0.0
+        for i in range(reps):
+            _COLD.fill_(float(i))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps * 1e-3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -70,7 +86,11 @@ def main():
     ap.add_argument("--gens", default="", help="comma list of RSU_FWD_GEN values to time side by side (fwd / bwd ops)")
     ap.add_argument("--dbg", default="", help="comma list of RSU_FWD_DBG values to time side by side")
     ap.add_argument("--ncu", type=int, default=0, help="CU budget the launches plan for (0: the library default, 256)")
+    ap.add_argument("--cold", action="store_true", help="write 512 MiB between repetitions: every launch starts with cold L2 / Infinity Cache, as in the step")
     args = ap.parse_args()
+    if args.cold:
+        global _COLD
+        _COLD = torch.empty(128 << 20, dtype=torch.float32, device=DEV)
     cfgs = [int(c) for c in args.cfgs.split(",")]
     gens = [g for g in args.gens.split(",") if g] or [None]
     dbgs = [g for g in args.dbg.split(",") if g] or [None]
