@@ -137,6 +137,13 @@ size_t rsu_packed_first_bytes(int Cout);
 int rsu_pack_conv_first(const float* w_hwio, void* packed, int Cout, rsu_stream_t stream);
 int rsu_conv_first_fwd(const void* in16, const void* packed, const float* b, void* y, int N, int H, int W, int Cout,
                        int dil, int ncu, rsu_stream_t stream);
+/* unet.py:22-23 AND unet.py:34-35,42-43 in one launch (no dropout: keep == 1): y = relu(conv3x3(conv1x1(x - 0.5, w0) + b0, W1, dilation) + b) straight from
+ * the f32 input x [N][H][W][3]; w0 f32 [3][3] ([ci][cj]), b0 f32 [3] (device pointers: color_space_adjust/kernel, /bias); packed, b, y as
+ * rsu_conv_first_fwd. The 16-channel tensor of rsu_color_adjust_fwd is neither written nor read (-58 MB and one launch per forward pass at
+ * B = 4, 572 px); the results are bit-identical to rsu_color_adjust_fwd(keep = 1) + rsu_conv_first_fwd. A training step still calls
+ * rsu_color_adjust_fwd (rsu_conv_first_bwd_weight reads its output), but may do so on another stream, off the forward pass's critical path. */
+int rsu_color_conv_first_fwd(const float* x, const float* w0, const float* b0, const void* packed, const float* b, void* y, int N, int H,
+                             int W, int Cout, int dil, int ncu, rsu_stream_t stream);
 /* weight/bias gradients of that conv and, through it, of color_space_adjust (no input-gradient pass is needed):
  * dw1 [3][3][3][Cout]; gx [9][12][Cout]: rows 0..8 gxc[t][3*ci+cj][co] = sum_pix m[pix+t][cj] (x-0.5)[pix+t][ci] dz[pix][co],
  * rows 9..11 gm[t][cj][co] = sum_pix m[pix+t][cj] dz[pix][co]. With W1 = this conv's kernel:

@@ -64,6 +64,7 @@ SIGNATURES = {
     "rsu_packed_first_bytes": (_sz, [_i]),
     "rsu_pack_conv_first": (_i, [_vp, _vp, _i, _vp]),
     "rsu_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsu_color_conv_first_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_conv_first_bwd_ws_floats": (_sz, [_i]),
     "rsu_conv_first_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsu_color_adjust_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp]),

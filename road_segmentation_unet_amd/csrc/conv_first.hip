@@ -23,6 +23,9 @@ __device__ __forceinline__ unsigned relu_pk(unsigned x) {
 }  // namespace
 
 struct ConvFirstParams {
+    const float* x;       // FUSED: the network input, f32 [N][H][W][3]; colour adjust (unet.py:22-23) is computed on the fly
+    const float* cw;      // FUSED: color_space_adjust kernel [ci][cj] (device)
+    const float* cb;      // FUSED: color_space_adjust bias [3] (device)
     const bf16_t* in16;   // [N][H][W][16]
     const bf16_t* wp;     // packed forward weights [1 chunk][9 taps][ntiles_w][64 lanes][8]
     const float* bias;    // [Cout] or null
@@ -33,7 +36,20 @@ struct ConvFirstParams {
     int npieces;          // N * Ho * ntx
 };
 
-__global__ void __launch_bounds__(256) k_conv_first_fwd(const ConvFirstParams p) {
+// FUSED: the B operand is made from the f32 input instead of read from in16 (k_color_adjust's output): a lane of the low channel half
+// loads its pixel's three colours (12 bytes), applies net0 = (x - 0.5) W0 + b0 with k_color_adjust's own expression (same fmaf chain, same
+// bf16 rounding: the kernel's results are bit-identical to the two-launch path) and supplies {net0, 0 x 5}; the high half supplies zeros
+// (its weights are zero in either path). in16 is then neither written nor read in a forward-only net (-58 MB and one launch per forward
+// pass); a training step still needs it for the first conv's weight gradient, but writes it off the critical path.
+// No dropout here (keep == 1 only: the mask of keep < 1 would be hashed nine times per pixel).
+#ifndef CF_TRS
+#define CF_TRS 1   // developer A/B switch: the output piece transposed through LDS into whole-pixel stores (0: the MFMA layout's stores of rounds 3-5)
+#endif
+template <bool FUSED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_conv_first_fwd(const ConvFirstParams p) {
+#if CF_TRS
+    __shared__ __attribute__((aligned(16))) char trs[4 * 2048];
+#endif
     const int lane = threadIdx.x & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int nwaves = gridDim.x * 4;
@@ -78,12 +94,51 @@ __global__ void __launch_bounds__(256) k_conv_first_fwd(const ConvFirstParams p)
         if (yy >= p.Ho) { ++nn; yy -= p.Ho; }
         n = (int)nn; y = yy; x0 = xt * 16;
     };
+    typedef __attribute__((ext_vector_type(3))) float f32x3;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, FUSED ? (int)((long)p.N * p.H * p.W * 12) : 0, 0x00020000);
+    unsigned xoff[5];     // FUSED: byte offset of the lane's pixel (3 floats) of k-step j; the high channel half asks for nothing
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int tap = min(2 * j + (g4 >> 1), 8), ky = tap / 3, kx = tap - 3 * ky;
+        xoff[j] = (g4 & 1) ? 0x80000000u : (unsigned)(((ky * p.W + kx) * p.dil + l15) * 12);
+    }
     auto load = [&](int t, bf16x8 (&fb)[5]) {
         int n, y, x0;
         decode(t, n, y, x0);
-        const unsigned soff = (unsigned)((((long)(n * p.H + y) * p.W + x0) * 16) * 2);
+        if constexpr (FUSED) {
+            const unsigned soff = (unsigned)(((long)(n * p.H + y) * p.W + x0) * 12);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) fb[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, voff[j], soff, 0));
+            for (int j = 0; j < 5; ++j) {
+                // (the three colours ride in the fragment's registers until the MFMAs need them: convert() below)
+                const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(rx, xoff[j], soff, 0));
+                fb[j] = __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], 0.f});
+            }
+        } else {
+            const unsigned soff = (unsigned)((((long)(n * p.H + y) * p.W + x0) * 16) * 2);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) fb[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, voff[j], soff, 0));
+        }
+    };
+    float cw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cbias[3] = {0.f, 0.f, 0.f};
+    if constexpr (FUSED) {   // (uniform addresses: scalar loads, twelve SGPRs for the life of the wave)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cw[i] = p.cw[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cbias[i] = p.cb[i];
+    }
+    auto convert = [&](bf16x8 (&fb)[5]) {   // FUSED: colours -> {bf16 net0[0..2], 0 x 5} (k_color_adjust's arithmetic, keep == 1)
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const f32x4 v = __builtin_bit_cast(f32x4, fb[j]);
+                const float xc[3] = {v[0] - 0.5f, v[1] - 0.5f, v[2] - 0.5f};
+                float f[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[c] = fmaf(xc[2], cw[6 + c], fmaf(xc[1], cw[3 + c], fmaf(xc[0], cw[c], cbias[c])));   // (x (m * inv) = 1 at keep == 1)
+                const u32x4 o = {pack_bf2(f[0], f[1]), pack_bf2(f[2], 0.f), 0u, 0u};
+                fb[j] = (g4 & 1) ? bf16x8{0, 0, 0, 0, 0, 0, 0, 0} : __builtin_bit_cast(bf16x8, o);
+            }
+        }
     };
     int t = wave;
     if (t >= p.npieces) return;
@@ -98,14 +153,46 @@ __global__ void __launch_bounds__(256) k_conv_first_fwd(const ConvFirstParams p)
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = binit[ct];
+        convert(fb);
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][ct], fb[j], acc[ct], 0, 0, 0);
         int n, y, x0;
         decode(t, n, y, x0);
-        const bool pok = x0 + l15 < p.Wo;
         const unsigned sbase = (unsigned)((((long)(n * p.Ho + y) * p.Wo + x0) * p.Cout + cb * 64) * 2);
+#if CF_TRS
+        // The MFMA's lane layout has lane (l15, g4) hold 16 bytes of pixel l15: a store instruction then writes sixteen 64-byte runs one pixel
+        // apart (the slow pattern of probes/probe_store_shapes.hip: ~3x the cycles of whole lines). This kernel is all stores (166 of 182 MB), so
+        // the piece's 16 pixels x 128 bytes take a turn through 2 KiB of wave-private LDS (16-byte slots XOR-swizzled by the pixel) and leave as
+        // two instructions of eight whole pixels each: 8 consecutive lanes = the 128 bytes of one pixel, 1 KiB contiguous where Cout = 64.
+        {
+            __attribute__((address_space(3))) char* wl = (__attribute__((address_space(3))) char*)trs + (threadIdx.x >> 6) * 2048;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                u32x4 r = {pack_bf2(acc[2 * pp][0], acc[2 * pp][1]), pack_bf2(acc[2 * pp][2], acc[2 * pp][3]),
+                           pack_bf2(acc[2 * pp + 1][0], acc[2 * pp + 1][1]), pack_bf2(acc[2 * pp + 1][2], acc[2 * pp + 1][3])};
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = relu_pk(r[i]);
+                }
+                *(__attribute__((address_space(3))) u32x4*)(wl + l15 * 128 + (((pp * 4 + g4) ^ (l15 & 7)) << 4)) = r;
+            }
+            // (a wave's LDS instructions execute in order: the reads below see the writes above; the asm keeps the COMPILER from moving a
+            // lane's read -- of another lane's slot -- in front of its own write, and the next piece's writes in front of these reads)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int q8 = lane & 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int P = (lane >> 3) + 8 * h;
+                const u32x4 r = *(const __attribute__((address_space(3))) u32x4*)(wl + P * 128 + ((q8 ^ (P & 7)) << 4));
+                const bool ok = (x0 + P < p.Wo) && (cb * 64 + q8 * 8 < p.Cout);
+                const unsigned vo = ok ? (unsigned)((P * p.Cout + q8 * 8) * 2) : 0x80000000u;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(vo), "s"(rout), "s"(sbase) : "memory");
+            }
+        }
+#else
+        const bool pok = x0 + l15 < p.Wo;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             u32x4 r = {pack_bf2(acc[2 * pp][0], acc[2 * pp][1]), pack_bf2(acc[2 * pp][2], acc[2 * pp][3]),
@@ -120,6 +207,7 @@ __global__ void __launch_bounds__(256) k_conv_first_fwd(const ConvFirstParams p)
             // an SGPR offset can reach the store's last lanes, and hipcc adds no wait state there -- DESIGN.md section 4)
             asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(r), "v"(vo), "s"(rout), "s"(sbase) : "memory");
         }
+#endif
         if (!more) break;
         t = tn;
 #pragma unroll
@@ -130,9 +218,11 @@ __global__ void __launch_bounds__(256) k_conv_first_fwd(const ConvFirstParams p)
 static unsigned floor_magic(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned)d); }
 
 // in16 [N][H][W][16] -> y [N][H - 2 dil][W - 2 dil][Cout]; wp = the layer's packed forward weights (ntiles_w 16-row tiles per tap)
+// x / cw / cb != null: the fused form (the colour adjust computed from the f32 input; cw [3][3], cb [3] device pointers); in16 is then unused
 hipError_t conv_first_fwd_launch(const void* in16, const void* wp, int ntiles_w, const float* bias, void* y, int N, int H, int W, int Cout, int dil,
-                                 int relu, int ncu, hipStream_t st) {
+                                 int relu, int ncu, hipStream_t st, const float* x, const float* cw, const float* cb) {
     ConvFirstParams p;
+    p.x = x; p.cw = cw; p.cb = cb;
     p.in16 = (const bf16_t*)in16; p.wp = (const bf16_t*)wp; p.bias = bias; p.y = (bf16_t*)y;
     p.N = N; p.H = H; p.W = W; p.Ho = H - 2 * dil; p.Wo = W - 2 * dil; p.Cout = Cout; p.dil = dil; p.relu = relu; p.ntiles_w = ntiles_w;
     p.ntx = (p.Wo + 15) / 16;
@@ -143,6 +233,7 @@ hipError_t conv_first_fwd_launch(const void* in16, const void* wp, int ntiles_w,
     p.npieces = (int)np;
     long blocks = (long)ncu * 3;                    // 3 blocks of 4 waves per CU: ~160 registers per lane
     if (blocks * 4 > np) blocks = (np + 3) / 4;
-    hipLaunchKernelGGL(k_conv_first_fwd, dim3((unsigned)blocks, (unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p);
+    if (x) hipLaunchKernelGGL(k_conv_first_fwd<true>, dim3((unsigned)blocks, (unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_conv_first_fwd<false>, dim3((unsigned)blocks, (unsigned)((Cout + 63) / 64)), dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -436,22 +436,25 @@ __global__ void __launch_bounds__(256) k_head(const bf16_t* __restrict__ act, co
 #pragma unroll
     for (int i = 0; i < 8; ++i) gw0[i] = gw1[i] = 0.f;
     const long niter = (npix + (long)gridDim.x * ppb - 1) / ((long)gridDim.x * ppb);
-    // two pixels per thread and trip, both loads requested before either is used: at 90 registers the kernel holds 5 waves per SIMD, and
-    // one 16-byte load per lane in flight is half of what the HBM latency needs (the sums keep the order of the pixels: same bits)
-    for (long it0 = 0; it0 < niter; it0 += 2) {
-        long pp[2];
-        bool okk[2];
-        u32x4 raw[2];
-        int labv[2] = {0, 0};
+    // HU pixels per thread and trip, all loads requested before any is used: the HBM latency (~2 us x 6 TB/s = 47 KB per CU in flight) wants more
+    // than the 16-32 KB that one or two 16-byte loads per lane of 16-20 resident waves give (round 5: two, 3.87 TB/s; round 6: four). The sums keep
+    // the order of the pixels: same bits.
+    constexpr int HU = 4;
+    for (long it0 = 0; it0 < niter; it0 += HU) {
+        long pp[HU];
+        bool okk[HU];
+        u32x4 raw[HU];
+        int labv[HU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < HU; ++u) {
+            labv[u] = 0;
             pp[u] = ((it0 + u) * gridDim.x + blockIdx.x) * ppb + threadIdx.x / LP;
             okk[u] = (it0 + u < niter) && pp[u] < npix;
             raw[u] = okk[u] ? *(const u32x4*)(act + pp[u] * C + sub * 8) : u32x4{0u, 0u, 0u, 0u};
             if (TRAIN) labv[u] = okk[u] ? (int)labels[pp[u]] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < HU; ++u) {
             const long p = pp[u];
             const bool ok = okk[u];
             float a[8];

@@ -95,7 +95,7 @@ bool igemm_ct_supports(int mode, int N, int H, int W, int Ca, int Cn);
 hipError_t igemm_ct_launch(int mode, const IgCtParams& p, int grid_x, hipStream_t st);
 // conv_first.hip: forward of the 16-channel first convolution, weights in registers, pixels straight from global memory
 hipError_t conv_first_fwd_launch(const void* in16, const void* wp, int ntiles_w, const float* bias, void* y, int N, int H, int W, int Cout, int dil,
-                                 int relu, int ncu, hipStream_t st);
+                                 int relu, int ncu, hipStream_t st, const float* x = nullptr, const float* cw = nullptr, const float* cb = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // igemm_wgrad: slab[z][tap][cs_off+cs][cf] = sum_{pix in split z} S[n][pix*stride + tap*dil][cs] * F[n][pix][cf]

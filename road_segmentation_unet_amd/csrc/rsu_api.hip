@@ -835,6 +835,17 @@ extern "C" int rsu_conv_first_fwd(const void* in16, const void* packed, const fl
                    ncu, (hipStream_t)stream);
 }
 
+extern "C" int rsu_color_conv_first_fwd(const float* x, const float* w0, const float* b0, const void* packed, const float* b, void* y, int N, int H,
+                                        int W, int Cout, int dil, int ncu, rsu_stream_t stream) {
+    if (!x || !w0 || !b0 || !packed || !y || Cout % 8 || H <= 2 * dil || W <= 2 * dil + 1 || (dil != 1 && dil != 2)) return RSU_EINVAL;
+    const int Ho = H - 2 * dil, Wo = W - 2 * dil;
+    const int n = launch_ncu(ncu);
+    if (n < 0) return RSU_EINVAL;
+    if ((long)N * Ho * Wo * Cout * 2 >= 0x7ffffff0L || (long)N * H * W * 12 >= 0x7ffffff0L) return RSU_E2BIG;
+    HIP_CHECK_RET(conv_first_fwd_launch(nullptr, packed, rup(Cout, 128) / 16, b, y, N, H, W, Cout, dil, 1, n, (hipStream_t)stream, x, w0, b0));
+    return RSU_OK;
+}
+
 extern "C" int rsu_conv2d_bwd_data_k(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,
                                      int W, int Cin_total, int ci_off, int ci_cnt, int Cout, int dil, int ncu, float* kws, size_t kws_floats, rsu_stream_t stream);
 extern "C" int rsu_conv2d_bwd_data(const void* dz, const void* packed_bwd, void* dx, const void* relu_src, int accumulate, int N, int H,

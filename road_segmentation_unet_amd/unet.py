@@ -498,7 +498,12 @@ class UNet:
                 return self.kws_side[k] if k < len(self.kws_side) else None
         return self.kws
 
-    def _conv_first(self, name, out, h, dil, st, in16=None):
+    def _conv_first(self, name, out, h, dil, st, in16=None, x=None):
+        if x is not None:
+            # colour adjust + first conv in one launch, straight from the f32 input (rsu.h rsu_color_conv_first_fwd; same bits, no dropout)
+            call("rsu_color_conv_first_fwd", _ptr(x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
+                 _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]), _ptr(out), out.shape[0], h, h, self.root, dil, self._ncu, st)
+            return
         call("rsu_conv_first_fwd", _ptr(self.in16 if in16 is None else in16), _ptr(self.pk[name + "/kernel", "fwd"]), _ptr(self.w[name + "/bias"]),
              _ptr(out), out.shape[0], h, h, self.root, dil, self._ncu, st)
 
@@ -528,8 +533,26 @@ class UNet:
 
         def add(f):
             steps.append(f)
-        add(lambda: call("rsu_color_adjust_fwd", _ptr(x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
-                         _ptr(in16), nb * S * S, keep, self.dropout_key(0), self._stream()))
+        # Without dropout the level-0 convs read the f32 input themselves (rsu_color_conv_first_fwd): a forward-only net never builds the
+        # 16-channel tensor, a training step still needs it for the first conv's weight gradient (rsu_conv_first_bwd_weight, the LAST
+        # launch of the backward pass) and writes it on the side stream, beside the first convs instead of in front of them.
+        # RSU_FIRST_FUSED=0: the two launches of rounds 1-5 (same bits).
+        fused_first = keep == 1.0 and os.environ.get("RSU_FIRST_FUSED", "1") != "0"
+        xin = x if fused_first else None
+
+        def color_adjust():
+            call("rsu_color_adjust_fwd", _ptr(x), _ptr(self.w["color_space_adjust/kernel"]), _ptr(self.w["color_space_adjust/bias"]),
+                 _ptr(in16), nb * S * S, keep, self.dropout_key(0), self._stream())
+        if not fused_first:
+            add(color_adjust)
+        elif self.training:
+            if len(self.wstreams) == 1:   # (one side stream: its later launches that read in16 follow in order; the main stream joins it before its own)
+                def color_adjust_side():
+                    with UNet._Side(self):
+                        color_adjust()
+                add(color_adjust_side)
+            else:
+                add(color_adjust)
         cur, h = None, S
         for i in range(L):
             last = i == L - 1
@@ -539,13 +562,13 @@ class UNet:
                 def twin(i=i, cur=cur, h=h):
                     with UNet._Side(self):
                         if i == 0:
-                            self._conv_first("conv_dilut_0/atrous_conv1", a["d1_0"], h, 2, self._stream(), in16)
+                            self._conv_first("conv_dilut_0/atrous_conv1", a["d1_0"], h, 2, self._stream(), in16, xin)
                         else:
                             self._conv("conv_dilut_%d/atrous_conv1" % i, [_src(cur, h, h)], h, a["d1_%d" % i], dil=2)
                         self._conv("conv_dilut_%d/atrous_conv2" % i, [_src(a["d1_%d" % i], h - 4, h - 4)], h - 4, a["d2_%d" % i], dil=2)
                 add(twin)
             if i == 0:
-                add(lambda h=h: self._conv_first("conv_0/conv1", a["c1_0"], h, 1, self._stream(), in16))
+                add(lambda h=h: self._conv_first("conv_0/conv1", a["c1_0"], h, 1, self._stream(), in16, xin))
             else:
                 add(lambda i=i, cur=cur, h=h: self._conv("conv_%d/conv1" % i, [_src(cur, h, h)], h, a["c1_%d" % i]))
             if last:

@@ -483,6 +483,32 @@ def test_color_adjust_and_first_conv(dil, keep):
     hu.assert_f32_close(hu.host(gx), ref_gx, "conv_first gx")
 
 
+@pytest.mark.parametrize("N,H,W,Cout,dil", [(2, 200, 203, 64, 1), (1, 40, 37, 16, 2), (3, 21, 50, 72, 1), (1, 64, 64, 160, 2), (1, 5, 19, 8, 1), (4, 572, 572, 64, 1)])
+def test_colour_adjust_fused_into_the_first_conv_gives_the_two_launches_bits(N, H, W, Cout, dil):
+    """rsu_color_conv_first_fwd (unet.py:22-23 + 34-35 from the f32 input in one launch: round 6) against
+    rsu_color_adjust_fwd(keep = 1) + rsu_conv_first_fwd: bit for bit (NaN-prefilled outputs), and against the oracle -- ragged row ends,
+    more pieces than waves, channel counts that are not multiples of 64, both dilations, and the c2 level-0 shape itself"""
+    rng = np.random.RandomState(5 + H)
+    x = rng.rand(N, H, W, 3).astype(np.float32)
+    w0, b0 = _rand(rng, 3, 3, scale=0.5), _rand(rng, 3, scale=0.1)
+    w1, b1 = _rand(rng, 3, 3, 3, Cout, scale=0.3), _rand(rng, Cout, scale=0.1)
+    xd_, w0d, b0d, w1d, b1d = hu.dev_f32(x), hu.dev_f32(w0), hu.dev_f32(b0), hu.dev_f32(w1), hu.dev_f32(b1)
+    in16 = torch.zeros((N, H, W, 16), dtype=torch.bfloat16, device=hu.DEV)
+    Ho, Wo = H - 2 * dil, W - 2 * dil
+    pk1 = torch.zeros(lib().rsu_packed_first_bytes(Cout) // 2, dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_pack_conv_first", hu.ptr(w1d), hu.ptr(pk1), Cout, hu.stream())
+    ya = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    yb = torch.full((N, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=hu.DEV)
+    call("rsu_color_adjust_fwd", hu.ptr(xd_), hu.ptr(w0d), hu.ptr(b0d), hu.ptr(in16), N * H * W, 1.0, 0, hu.stream())
+    call("rsu_conv_first_fwd", hu.ptr(in16), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(ya), N, H, W, Cout, dil, 0, hu.stream())
+    call("rsu_color_conv_first_fwd", hu.ptr(xd_), hu.ptr(w0d), hu.ptr(b0d), hu.ptr(pk1), hu.ptr(b1d), hu.ptr(yb), N, H, W, Cout, dil, 0, hu.stream())
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(yb.float()).any())
+    assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
+    if H <= 203:   # (the oracle's conv on the device's own bf16 net0, as in test_color_adjust_and_first_conv: a 1-ulp flip of net0 is not this kernel's)
+        hu.assert_bf16_close(hu.host(yb), U.conv2d_fwd(hu.host(in16)[..., 0:3], hu.q(w1), b1, dil=dil), "colour adjust + first conv, one launch")
+
+
 @pytest.mark.parametrize("N,H,W,Cout,dil", [(2, 200, 203, 64, 1), (1, 40, 37, 16, 2), (3, 21, 50, 72, 1), (1, 64, 64, 160, 2), (1, 5, 19, 8, 1)])
 def test_first_conv_kernel_against_oracle_and_generic_launch(N, H, W, Cout, dil, monkeypatch):
     """k_conv_first_fwd (weights in registers, pixels straight from global memory; the default of rsu_conv_first_fwd) against the oracle and

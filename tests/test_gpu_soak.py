@@ -56,13 +56,14 @@ def test_two_stream_schedule_does_not_change_the_numbers(monkeypatch):
     gradients grouped into few launches (RSU_WG_GROUP: the default on one stream is ONE group behind the pass)."""
     from road_segmentation_unet_amd.unet import UNet
 
-    def run(single_stream, split="0", group="0"):
+    def run(single_stream, split="0", group="0", budget=None):
         monkeypatch.setenv("RSU_SPLIT_CHIP", split)
         if group is None:
             monkeypatch.delenv("RSU_WG_GROUP", raising=False)
         else:
             monkeypatch.setenv("RSU_WG_GROUP", group)
         m = UNet(4, 32, True, 2, 204, seed=11, training=True)
+        m.backward_cu_budget = budget
         if single_stream:
             m.wstream, m.wstreams = None, []
         g = torch.Generator(device="cpu").manual_seed(3)
@@ -84,6 +85,12 @@ def test_two_stream_schedule_does_not_change_the_numbers(monkeypatch):
         c = run(single, split, group)
         assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), (single, split, group)
         assert torch.equal(c, run(single, split, group)), "a grouped schedule must repeat bit for bit"
+    # the budgets a data-parallel run offers (dist.EXCHANGE_CANDIDATES; round 6: 240 = 112 + 128, 224 = 96 + 128, 208 = 104 + 104): the weight gradients
+    # keep the summation order of their CU share, the backward-data launches give the same bits at any share
+    for budget in (240, 224, 208):
+        c = run(False, "128,128", "0", budget)
+        assert float((a - c).abs().max()) <= 1e-5 * float(a.abs().max()), budget
+        assert torch.equal(c, run(False, "128,128", "0", budget)), "a budgeted schedule must repeat bit for bit"
 
 
 def test_measured_tile_shapes_do_not_change_the_numbers():
