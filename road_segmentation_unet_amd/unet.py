@@ -533,11 +533,13 @@ class UNet:
 
         def add(f):
             steps.append(f)
-        # Without dropout the level-0 convs read the f32 input themselves (rsu_color_conv_first_fwd): a forward-only net never builds the
-        # 16-channel tensor, a training step still needs it for the first conv's weight gradient (rsu_conv_first_bwd_weight, the LAST
-        # launch of the backward pass) and writes it on the side stream, beside the first convs instead of in front of them.
-        # RSU_FIRST_FUSED=0: the two launches of rounds 1-5 (same bits).
-        fused_first = keep == 1.0 and os.environ.get("RSU_FIRST_FUSED", "1") != "0"
+        # A forward-only net without dropout reads the f32 input in the level-0 convs themselves (rsu_color_conv_first_fwd: one launch, the
+        # 16-channel tensor is never built, same bits). A training step needs that tensor for the first conv's weight gradient anyway, and the
+        # first conv reads it back hot from the Infinity Cache: measured (profiles/r06/kernel_stats_fused_first.md), the fused launch beside a
+        # colour-adjust launch on the side stream takes 66 us against 14.5 + 48 us of the two launches in a row -- training keeps the two.
+        # RSU_FIRST_FUSED=0: never fuse; =2: fuse in training steps too (the measured variant).
+        ff = os.environ.get("RSU_FIRST_FUSED", "1")
+        fused_first = keep == 1.0 and (ff == "2" or (ff != "0" and not self.training))
         xin = x if fused_first else None
 
         def color_adjust():
