@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RSU_BENCH_WORKLOAD", "c2"), choices=["c2", "c3", "c4"],
                     help="c2: num_layers=5 (headline); c3: num_layers=6 dilated, one patch per step (the reference's final model); "
                          "c4: num_layers=6, the per-GPU share of the data-parallel configuration")
-    ap.add_argument("--sustain_seconds", type=float, default=2.0, help="length of the extra steady-state loop (0: skip)")
+    ap.add_argument("--sustain_seconds", type=float, default=5.0, help="length of the extra steady-state loop (0: skip); 5 s: longer than the period of the driver's GPU-busy sampler (VERDICT r5 item 14)")
     ap.add_argument("--prime_seconds", type=float, default=1.0,
                     help="untimed steps run for this long in front of the W warm-up steps: clocks and power reach their steady state (0: skip)")
     ap.add_argument("--cpu_sample_patch", type=int, default=196)

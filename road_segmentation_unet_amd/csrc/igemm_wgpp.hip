@@ -33,8 +33,18 @@ constexpr int sched_first(int sch, int ph) {
     for (int i = 0; i < ph; ++i) n += sched_count(sch, i);
     return n;
 }
+// WGPP_NT / WG64_NT (developer A/B switches, round 6; VERDICT r5 item 1 "try the nt policy on the weight-gradient kernels' once-read activation
+// pieces"): the operand streams of igemm_wgpp / igemm_wgp64 loaded with the non-temporal hint, so that they displace less of what the
+// backward-data kernel on the same XCD keeps in its L2. Measured: profiles/r06/ab_wgnt.txt.
+#ifndef WGPP_NT
+#define WGPP_NT 0
+#endif
+#ifndef WG64_NT
+#define WG64_NT 0
+#endif
+template <int NT = 0>
 __device__ __forceinline__ void bdma16w(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, NT ? 2 : 0);
 }
 }  // namespace
 
@@ -169,7 +179,7 @@ __device__ __forceinline__ void igemm_wgpp_body(const P& p, __attribute__((addre
                 const int limx = ty < T.ry ? T.rx - wtx0 : 0, limc = limcF - (I >> 1) * 64;
                 vo = (l8 < limx && cswz8 < limc) ? lvF : RSU_SENT;
             }
-            bdma16w(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
+            bdma16w<WGPP_NT>(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
         } else if constexpr (I < NFW + NSW) {
             constexpr int Q = I - NFW;
             const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
@@ -181,7 +191,7 @@ __device__ __forceinline__ void igemm_wgpp_body(const P& p, __attribute__((addre
                 const int limx = (hp0 < NPIX && rr < T.ry + 2) ? T.rx + 2 - cc0 : 0;
                 vo = (l8 < limx && cswz8 < limcS) ? lvS : RSU_SENT;
             }
-            bdma16w(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
+            bdma16w<WGPP_NT>(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
         }
     };
     auto bar = [&]() {
@@ -465,7 +475,7 @@ __device__ __forceinline__ void igemm_wgp64_body(const P& p, __attribute__((addr
                 const int limx = ty < T.ry ? T.rx - wtx0 : 0;
                 vo = (l8 < limx && cswz8 < limcF) ? lvF : RSU_SENT;
             }
-            bdma16w(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
+            bdma16w<WG64_NT>(rf, vo, soff, (void*)(lds + buf * SLOT + (I * NW + wave) * 1024));
         } else if constexpr (I < NP) {
             constexpr int Q = I - NFW;
             const __amdgpu_buffer_rsrc_t rs = mk(p.S.ptr);
@@ -477,7 +487,7 @@ __device__ __forceinline__ void igemm_wgp64_body(const P& p, __attribute__((addr
                 const int limx = (hp0 < NPIX && rr < T.ry + 2) ? T.rx + 2 - cc0 : 0;
                 vo = (l8 < limx && cswz8 < limcS) ? lvS : RSU_SENT;
             }
-            bdma16w(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
+            bdma16w<WG64_NT>(rs, vo, soff, (void*)(lds + buf * SLOT + FBUF + (Q * NW + wave) * 1024));
         }
     };
     auto bar = [&]() {
