@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -25,6 +26,35 @@ __device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& a, const bf16x
 }
 __device__ __forceinline__ void mfma16a(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// ---- round 6: an R interval with its instruction order pinned (modes 7 / 8 below)
+template <int R>
+__device__ __forceinline__ void order_rd(bf16x8 (&ka)[3][4], bf16x8 (&kb)[3][4], unsigned ldsa) {
+    constexpr int off = R < 12 ? R * 1024 : 12288 + (R - 12) * 1024;
+    if constexpr (R < 12) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ka[R / 4][R % 4]) : "v"(ldsa), "n"(off) : "memory");
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kb[(R - 12) / 4][R % 4]) : "v"(ldsa), "n"(off) : "memory");
+}
+__device__ __forceinline__ void order_alu(int& vv, int& sc) {
+    asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5\n\ts_add_u32 %1, %1, 3\n\ts_xor_b32 %1, %1, 5" : "+v"(vv), "+s"(sc)::"memory");
+}
+template <int ND>
+__device__ __forceinline__ void order_dma(const bf16x8* src, __attribute__((address_space(3))) char* lds, int it, int lane, int wave, int d) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((it * ND + d) * 64 + lane) % 4096),
+                                     (__attribute__((address_space(3))) void*)(lds + 65536 + (wave * 8 + d) * 1024), 16, 0, 0);
+    asm volatile("" ::: "memory");
+}
+template <int MODE, int ND, int R>
+__device__ __forceinline__ void order_seq(bf16x8 (&ka)[3][4], bf16x8 (&kb)[3][4], unsigned ldsa, int& vv, int& sc, const bf16x8* src,
+                                          __attribute__((address_space(3))) char* lds, int it, int lane, int wave) {
+    if constexpr (R < 24) {
+        order_rd<R>(ka, kb, ldsa);
+        if constexpr (MODE == 7) {
+            if constexpr ((R & 1) == 1 && R / 2 < 10) order_alu(vv, sc);
+            if constexpr ((R & 3) == 3 && R / 4 < ND) order_dma<ND>(src, lds, it, lane, wave, R / 4);
+        }
+        order_seq<MODE, ND, R + 1>(ka, kb, ldsa, vv, sc, src, lds, it, lane, wave);
+    }
 }
 
 template <int MODE, int NM, int NR, int ND, bool BIG, bool AGPR>
@@ -43,11 +73,11 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((__attribute__((address_space(3))) bf16x8*)lds)[i & 4095] = src[i & 4095];
     __syncthreads();
     constexpr int NACC = BIG ? NM / 2 : NM;
-    f32x4 acc[BIG ? 1 : (MODE == 6 ? 16 : NM)];
+    f32x4 acc[BIG ? 1 : (MODE >= 6 ? 16 : NM)];
     f32x16 accb[BIG ? NM / 2 : 1];
     if constexpr (!BIG) {
 #pragma unroll
-        for (int i = 0; i < (MODE == 6 ? 16 : NM); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (MODE >= 6 ? 16 : NM); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
@@ -55,7 +85,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
             for (int j = 0; j < 16; ++j) accb[i][j] = 0.f;
     }
     bf16x8 ka[3][4], kb[3][4];
-    if constexpr (MODE == 6) {
+    if constexpr (MODE >= 6) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -64,8 +94,23 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
                 kb[t][i] = fb[i];
             }
     }
+    int mit = 0;
     auto mround = [&]() {
-        if constexpr (MODE == 6) {
+        if constexpr (MODE == 9) {   // round 6: the multiplying wave issues the LDS-DMA pieces itself, one behind every 48 / ND MFMAs
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        mfma16(acc[ct * 4 + pt], ka[t][ct], kb[t][pt]);
+                        constexpr int every = ND > 0 ? 48 / ND : 1000;
+                        const int idx = (t * 4 + pt) * 4 + ct;
+                        if (ND > 0 && idx % every == every - 1 && idx / every < ND) order_dma<ND>(src, lds, mit, lane, wave, idx / every);
+                    }
+            return;
+        }
+        if constexpr (MODE == 6 || MODE == 7 || MODE == 8) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -95,6 +140,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
     if (MODE >= 2 && grp == 1) bar();
     t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
+        mit = it;
         if constexpr (MODE == 0) {
             mround();
         } else if constexpr (MODE == 1) {
@@ -131,6 +177,35 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            if constexpr (MODE == 9) {
+                const unsigned ldsa = (unsigned)((it & 1) * 32768 + lane * 16);
+                int vv = lane + it;
+                int sc = __builtin_amdgcn_readfirstlane(it);
+                order_seq<8, 0, 0>(ka, kb, ldsa, vv, sc, src, lds, it, lane, wave);
+#pragma unroll
+                for (int d = 0; d < 10; ++d) order_alu(vv, sc);
+                asm volatile("" ::"v"(vv), "s"(sc));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if constexpr (MODE == 7 || MODE == 8) {
+                // round 6: the same R interval as mode 6 (24 ds_read_b128, 10 ALU blocks of 3 vector + 4 scalar, ND LDS-DMA pieces) with the ORDER pinned by
+                // inline asm: mode 8 = the order igemm_pp's intervals compile to (all reads, then the ALU, then the pieces), mode 7 = interleaved (an ALU
+                // block behind every second read, a piece behind every fourth): does a wave stalled on the LDS queue lose issue time other categories could use?
+                const unsigned ldsa = (unsigned)((it & 1) * 32768 + lane * 16);
+                int vv = lane + it;
+                int sc = __builtin_amdgcn_readfirstlane(it);
+                order_seq<MODE, ND, 0>(ka, kb, ldsa, vv, sc, src, lds, it, lane, wave);
+                if constexpr (MODE == 8) {
+#pragma unroll
+                    for (int d = 0; d < 10; ++d) order_alu(vv, sc);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) order_dma<ND>(src, lds, it, lane, wave, d);
+                }
+                asm volatile("" ::"v"(vv), "s"(sc));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             if constexpr (MODE == 5) {
                 int vv = lane + it;
                 int sc = __builtin_amdgcn_readfirstlane(it);
@@ -158,7 +233,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* src, float* out, unsi
     float s = 0.f;
     if constexpr (!BIG) {
 #pragma unroll
-        for (int i = 0; i < (MODE == 6 ? 16 : NM); ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        for (int i = 0; i < (MODE >= 6 ? 16 : NM); ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     } else {
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
@@ -190,7 +265,7 @@ static void run(const char* name, int threads, int blocks, const bf16x8* src, fl
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> hl(blocks * 8);
     hipMemcpy(hl.data(), cyc, hl.size() * 8, hipMemcpyDeviceToHost);
-    const double flops = (double)blocks * (threads / 64) * long_iters * (MODE == 6 ? 48 : NM) * 16384.0;
+    const double flops = (double)blocks * (threads / 64) * long_iters * (MODE >= 6 ? 48 : NM) * 16384.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
     const double ghz = (double)hl[0] / (ms * 1e-3) / 1e9;  // counter ticks per second over the long run
     hipLaunchKernelGGL((probe<MODE, NM, NR, ND, BIG, AGPR>), dim3(blocks), dim3(threads), 96 * 1024, 0, src, out, cyc, iters, threads);
@@ -200,7 +275,7 @@ static void run(const char* name, int threads, int blocks, const bf16x8* src, fl
     const int waves = threads / 64;
     // MFMA work per SIMD per round: waves/4 waves x NM MFMAs x 16 cycles; ping-pong modes run 2 rounds (G0's and G1's) per iteration
     const double per_iter = (double)h[0] / iters;
-    const double ideal = MODE == 6 ? 1536.0 : MODE >= 2 ? 2.0 * NM * 16.0 : (double)(waves > 4 ? waves / 4 : 1) * NM * 16.0;
+    const double ideal = MODE >= 6 ? 1536.0 : MODE >= 2 ? 2.0 * NM * 16.0 : (double)(waves > 4 ? waves / 4 : 1) * NM * 16.0;
     printf("%-52s blocks %3d  cyc/iter %8.1f  ideal %5.0f  util %5.1f %% | wall %7.1f TFLOP/s, counter %.2f GHz\n", name, blocks, per_iter, ideal,
            100.0 * ideal / per_iter, tf, ghz);
 }
@@ -229,6 +304,18 @@ int main() {
             run<4, 16, 8, 2, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 2 LDS-DMA", 512, blocks, src, out, cyc);
             run<4, 16, 8, 4, false, false>("ping-pong, 16 x 16x16x32 | 8 ds_read + 4 LDS-DMA", 512, blocks, src, out, cyc);
             run<4, 16, 8, 4, true, false>("ping-pong, 8 x 32x32x16 | 8 ds_read + 4 LDS-DMA", 512, blocks, src, out, cyc);
+        }
+        return 0;
+    }
+    if (getenv("PROBE_ORDER")) {   // round 6: does the ORDER of an R interval's instructions matter? (profiles/r06/r_interval_order.txt)
+        for (int blocks : {1, 256}) {
+            run<6, 48, 24, 6, false, false>("mode 6 (compiler's order): 24 ds_read + 70 ALU + 6 LDS-DMA", 512, blocks, src, out, cyc);
+            run<8, 48, 24, 6, false, false>("asm, grouped: 24 ds_read | 70 ALU | 6 LDS-DMA", 512, blocks, src, out, cyc);
+            run<7, 48, 24, 6, false, false>("asm, interleaved: ALU behind every 2nd read, DMA every 4th", 512, blocks, src, out, cyc);
+            run<9, 48, 24, 6, false, false>("asm, 6 LDS-DMA issued by the MULTIPLYING wave (1 per 8 MFMAs)", 512, blocks, src, out, cyc);
+            run<9, 48, 24, 12, false, false>("asm, 12 LDS-DMA issued by the multiplying wave (1 per 4 MFMAs)", 512, blocks, src, out, cyc);
+            run<8, 48, 24, 0, false, false>("asm, grouped, no LDS-DMA", 512, blocks, src, out, cyc);
+            run<7, 48, 24, 0, false, false>("asm, interleaved, no LDS-DMA", 512, blocks, src, out, cyc);
         }
         return 0;
     }
