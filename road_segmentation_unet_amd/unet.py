@@ -93,6 +93,18 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def cu_shares(full, parts):
+    """CUs the backward streams plan for: `parts` = RSU_SPLIT_CHIP as integers ([main, side, ...] out of 256), `full` = the CUs the backward pass
+    may use in all (256, or a data-parallel budget that leaves CUs to RCCL's channel workgroups). With the default 128 + 128 and a budget of
+    224 .. 255 the weight-gradient stream keeps its 128 -- its pixel splits and workgroup counts per XCD are powers of two: 120 + 120 costs c2
+    8 % and c4 5 %, 112 + 128 costs 1.7 % and 3.6 % (profiles/r06/dp_budget.txt) -- and the backward-data stream, whose persistent kernels walk
+    tile lists of any length, takes the rest. Below 224 the backward-data stream would starve (80 + 128: -16 %): shares in proportion, in
+    steps of 8, at least 32 -- as for every other setting."""
+    if full < 256 and list(parts) == [128, 128] and full >= 224:
+        return [full - 128, 128]
+    return [max(32, v * full // 256 // 8 * 8) for v in parts]
+
+
 def _src(t, h, w):
     """window (h, w) centred in NHWC tensor t (crop offset floor((H-h)/2), unet.py:70-83)"""
     H, W, C = t.shape[1], t.shape[2], t.shape[3]
@@ -394,14 +406,7 @@ class UNet:
         if parts is None:
             self._ncu = full if self.backward_cu_budget else 0
             return
-        if full < 256 and len(parts) == 2 and parts == [128, 128] and full >= 224:
-            # a data-parallel budget (CUs left to RCCL's channel workgroups): the weight-gradient stream keeps its 128 -- its pixel splits and
-            # workgroup counts per XCD are powers of two: 120 + 120 costs c2 8 % and c4 5 %, 112 + 128 costs 1.7 % and 3.6 % (profiles/r06/
-            # dp_budget.txt) -- and the backward-data stream, whose persistent kernels walk tile lists of any length, takes the rest. Below 224
-            # the backward-data stream would starve (80 + 128: -16 %): the proportional split again
-            parts = [full - 128, 128]
-        else:
-            parts = [max(32, v * full // 256 // 8 * 8) for v in parts]
+        parts = cu_shares(full, parts)
         self._split = (full, parts[0], parts[1:])
         # the main stream keeps the whole budget until the first weight-gradient launch has gone to the side stream
         self._ncu = full if self.backward_cu_budget else 0

@@ -111,3 +111,20 @@ def test_rsu_plan_matches_the_python_shape_table():
         small = (_lib.RsuPlanRow * 2)()
         assert lib.rsu_plan(L, root, P, dil, 4, small, 2, ctypes.byref(n), None) == -12  # RSU_ENOMEM, count still reported
     assert lib.rsu_plan(5, 64, 390, 0, 4, None, 0, ctypes.byref(n), None) == -22  # the reference's input_size assertion
+
+
+def test_cu_shares_of_a_data_parallel_budget():
+    """unet.cu_shares (round 6): a budget of 224 .. 255 CUs keeps the weight-gradient stream at its 128 CUs and gives the backward-data stream the rest;
+    256, smaller budgets and every non-default RSU_SPLIT_CHIP are shared out in proportion, in steps of 8, at least 32 CUs per stream (pure host logic)"""
+    from road_segmentation_unet_amd.unet import cu_shares
+    assert cu_shares(256, [128, 128]) == [128, 128]
+    assert cu_shares(240, [128, 128]) == [112, 128]
+    assert cu_shares(224, [128, 128]) == [96, 128]
+    assert cu_shares(208, [128, 128]) == [104, 104]
+    assert cu_shares(192, [128, 128]) == [96, 96]
+    assert cu_shares(240, [112, 128]) == [104, 120]          # an explicit setting is scaled, not overridden
+    assert cu_shares(256, [128, 64, 64]) == [128, 64, 64]
+    assert cu_shares(64, [128, 128]) == [32, 32]
+    for full in (256, 240, 224, 208, 192, 128):
+        p = cu_shares(full, [128, 128])
+        assert sum(p) <= full and min(p) >= 32 and all(v % 8 == 0 for v in p)
